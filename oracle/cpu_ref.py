@@ -1,0 +1,222 @@
+"""CPU restatement (PyTorch-CPU, fp32 or fp64) of the reference's hot path.
+
+TEST INFRASTRUCTURE ONLY -- see ``oracle/__init__.py``.
+
+This is a *functional* restatement: every function takes the parameter tensors
+explicitly (keyed by the reference's ``state_dict`` names) and is written from
+the maths in SURVEY.md Appendix A.  Backward passes come from autograd over
+these functions (the reference also relies on autograd).  It is pinned against
+the real reference modules by ``tests/golden/gen_golden.py`` (run in the
+authoring container, where /root/reference is importable) and by the committed
+fixtures under ``tests/golden`` (``tests/test_oracle_golden.py``).
+
+Reference citations (paths relative to /root/reference):
+  SEBlock            src/unet.py:6-17
+  SpatialGate        src/unet.py:19-29
+  ConvBlock          src/unet.py:32-49
+  Up                 src/unet.py:60-69
+  ConvLSTMCell       src/convlstm.py:5-19
+  ConvLSTM           src/convlstm.py:21-35
+  DownPoolEnc        src/unet_convlstm_attention.py:18-25
+  AttUNetConvLSTM    src/unet_convlstm_attention.py:27-104
+  training_step      main_final.py:556-561   (MSELoss, :544)
+  Adam               main_final.py:737-747   (torch.optim.Adam defaults)
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+Params = Dict[str, Tensor]
+
+__all__ = [
+    "se_block", "spatial_gate", "conv_block", "down_pool_enc", "up_block",
+    "convlstm_cell", "convlstm", "model_forward", "training_loss",
+    "adam_reference_step", "param_shapes", "closed_form_params", "GN_GROUPS", "GN_EPS",
+]
+
+GN_GROUPS = 8       # nn.GroupNorm(8, c_out), src/unet.py:37,39
+GN_EPS = 1e-5       # torch default
+
+
+# ----------------------------------------------------------------------------- blocks
+def se_block(x: Tensor, w1: Tensor, w2: Tensor) -> Tensor:
+    """x * sigmoid(W2 relu(W1 mean_hw(x)))  -- src/unet.py:16-17 (both 1x1 convs bias-free)."""
+    pooled = x.mean(dim=(2, 3), keepdim=True)
+    hidden = F.relu(F.conv2d(pooled, w1))
+    scale = torch.sigmoid(F.conv2d(hidden, w2))
+    return x * scale
+
+
+def spatial_gate(x: Tensor, w7: Tensor) -> Tensor:
+    """x * sigmoid(conv7x7([mean_c x, amax_c x]))  -- src/unet.py:26-29 (cat order avg, max)."""
+    avg = x.mean(dim=1, keepdim=True)
+    mxx = x.amax(dim=1, keepdim=True)
+    gate = torch.sigmoid(F.conv2d(torch.cat([avg, mxx], dim=1), w7, padding=3))
+    return x * gate
+
+
+def _gn_silu(x: Tensor, gamma: Tensor, beta: Tensor) -> Tensor:
+    return F.silu(F.group_norm(x, GN_GROUPS, gamma, beta, GN_EPS))
+
+
+def conv_block(x: Tensor, p: Params, prefix: str) -> Tensor:
+    """conv3x3 -> GN(8) -> SiLU -> conv3x3 -> GN(8) -> SiLU -> SE -> SpatialGate (src/unet.py:35-49)."""
+    y = F.conv2d(x, p[prefix + "body.0.weight"], padding=1)
+    y = _gn_silu(y, p[prefix + "body.1.weight"], p[prefix + "body.1.bias"])
+    y = F.conv2d(y, p[prefix + "body.3.weight"], padding=1)
+    y = _gn_silu(y, p[prefix + "body.4.weight"], p[prefix + "body.4.bias"])
+    y = se_block(y, p[prefix + "se.fc.0.weight"], p[prefix + "se.fc.2.weight"])
+    y = spatial_gate(y, p[prefix + "spat.conv.weight"])
+    return y
+
+
+def down_pool_enc(x: Tensor, p: Params, prefix: str) -> Tensor:
+    """ConvBlock(MaxPool2d(2)(x))  -- src/unet_convlstm_attention.py:24-25."""
+    return conv_block(F.max_pool2d(x, 2), p, prefix + "conv.")
+
+
+def up_block(x: Tensor, skip: Tensor, p: Params, prefix: str) -> Tensor:
+    """ConvTranspose2d(2, s=2) -> cat([up, skip]) -> ConvBlock  -- src/unet.py:66-69."""
+    up = F.conv_transpose2d(x, p[prefix + "up.weight"], p[prefix + "up.bias"], stride=2)
+    return conv_block(torch.cat([up, skip], dim=1), p, prefix + "conv.")
+
+
+def convlstm_cell(x: Tensor, h: Tensor, c: Tensor, w: Tensor, b: Tensor) -> Tuple[Tensor, Tensor]:
+    """One ConvLSTM step, gate order i,f,o,g, input order [x,h]  -- src/convlstm.py:11-19."""
+    gates = F.conv2d(torch.cat([x, h], dim=1), w, b, padding=w.shape[-1] // 2)
+    i, f, o, g = gates.chunk(4, dim=1)
+    i, f, o = torch.sigmoid(i), torch.sigmoid(f), torch.sigmoid(o)
+    g = torch.tanh(g)
+    c_next = f * c + i * g
+    h_next = o * torch.tanh(c_next)
+    return h_next, c_next
+
+
+def convlstm(x_seq: Tensor, w: Tensor, b: Tensor) -> Tensor:
+    """x_seq [T,B,C,h,w] -> stacked hidden states [T,B,C_hid,h,w]; h0=c0=0 (src/convlstm.py:27-35)."""
+    c_hid = w.shape[0] // 4
+    h = torch.zeros_like(x_seq[0, :, :c_hid])
+    c = torch.zeros_like(h)
+    outs: List[Tensor] = []
+    for t in range(x_seq.shape[0]):
+        h, c = convlstm_cell(x_seq[t], h, c, w, b)
+        outs.append(h)
+    return torch.stack(outs)
+
+
+# ----------------------------------------------------------------------------- whole model
+def model_forward(p: Params, x_seq: Tensor, return_intermediates: bool = False):
+    """AttUNetConvLSTM.forward (src/unet_convlstm_attention.py:60-104).
+
+    x_seq [B,T,C,H,W] -> [B,out_ch,H,W].  ``post_conv.*`` is never used (as in the reference).
+    The frame loop is kept as a loop (not folded into the batch) so this stays a literal restatement.
+    """
+    B, T = x_seq.shape[:2]
+    s1s, s2s, s3s, s4s = [], [], [], []
+    for t in range(T):
+        x_t = x_seq[:, t]
+        s1 = conv_block(x_t, p, "enc1.")
+        s2 = down_pool_enc(s1, p, "enc2.")
+        s3 = down_pool_enc(s2, p, "enc3.")
+        s4 = down_pool_enc(s3, p, "enc4.")
+        s1s.append(s1); s2s.append(s2); s3s.append(s3); s4s.append(s4)
+    lstm_in = torch.stack(s4s, dim=0)
+    lstm_out = convlstm(lstm_in, p["convlstm.cell.conv.weight"], p["convlstm.cell.conv.bias"])
+    bott = lstm_out[-1]
+    s1k = torch.stack(s1s, 0).mean(0)
+    s2k = torch.stack(s2s, 0).mean(0)
+    s3k = torch.stack(s3s, 0).mean(0)
+    d3 = up_block(bott, s3k, p, "up3.")
+    d2 = up_block(d3, s2k, p, "up2.")
+    d1 = up_block(d2, s1k, p, "up1.")
+    out = F.conv2d(d1, p["head.weight"], p["head.bias"])
+    if return_intermediates:
+        return out, dict(s1=s1s, s2=s2s, s3=s3s, s4=s4s, lstm_out=lstm_out, d3=d3, d2=d2, d1=d1)
+    return out
+
+
+def training_loss(p: Params, x_seq: Tensor, y: Tensor) -> Tensor:
+    """training_step (main_final.py:556-561): nn.MSELoss()(model(x), y)."""
+    return F.mse_loss(model_forward(p, x_seq), y)
+
+
+def adam_reference_step(param: Tensor, grad: Tensor, m: Tensor, v: Tensor, step: int, lr: float,
+                        beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
+                        weight_decay: float = 0.0) -> None:
+    """In-place torch.optim.Adam update (coupled L2), SURVEY Appendix A. ``step`` counts from 1."""
+    g = grad if weight_decay == 0.0 else grad + weight_decay * param
+    m.mul_(beta1).add_(g, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    param.addcdiv_(m, denom, value=-lr / bc1)
+
+
+# ----------------------------------------------------------------------------- parameter inventory
+def param_shapes(in_ch: int, out_ch: int, base: int) -> "Dict[str, Tuple[int, ...]]":
+    """The reference's 75-entry state_dict (names, shapes, registration order).
+
+    AttUNetConvLSTM.__init__, src/unet_convlstm_attention.py:27-56.
+    """
+    shapes: Dict[str, Tuple[int, ...]] = {}
+
+    def block(prefix: str, ci: int, co: int) -> None:
+        shapes[prefix + "body.0.weight"] = (co, ci, 3, 3)
+        shapes[prefix + "body.1.weight"] = (co,)
+        shapes[prefix + "body.1.bias"] = (co,)
+        shapes[prefix + "body.3.weight"] = (co, co, 3, 3)
+        shapes[prefix + "body.4.weight"] = (co,)
+        shapes[prefix + "body.4.bias"] = (co,)
+        shapes[prefix + "se.fc.0.weight"] = (co // 8, co, 1, 1)
+        shapes[prefix + "se.fc.2.weight"] = (co, co // 8, 1, 1)
+        shapes[prefix + "spat.conv.weight"] = (1, 2, 7, 7)
+
+    b = base
+    block("enc1.", in_ch, b)
+    block("enc2.conv.", b, 2 * b)
+    block("enc3.conv.", 2 * b, 4 * b)
+    block("enc4.conv.", 4 * b, 8 * b)
+    shapes["convlstm.cell.conv.weight"] = (16 * b, 12 * b, 3, 3)
+    shapes["convlstm.cell.conv.bias"] = (16 * b,)
+    shapes["post_conv.0.weight"] = (4 * b, 4 * b, 3, 3)
+    shapes["post_conv.0.bias"] = (4 * b,)
+    for name, ci, cs, co in (("up3.", 4 * b, 4 * b, 4 * b), ("up2.", 4 * b, 2 * b, 2 * b), ("up1.", 2 * b, b, b)):
+        shapes[name + "up.weight"] = (ci, co, 2, 2)
+        shapes[name + "up.bias"] = (co,)
+        block(name + "conv.", co + cs, co)
+    shapes["head.weight"] = (out_ch, b, 1, 1)
+    shapes["head.bias"] = (out_ch,)
+    return shapes
+
+
+def closed_form_params(in_ch: int, out_ch: int, base: int, dtype=torch.float32, salt: int = 0) -> Params:
+    """Deterministic, RNG-free parameter fill (used for fixtures: no dependence on torch's RNG stream).
+
+    Every tensor gets ``amp * sin(k * 0.7 + phase)`` with ``amp = 1/sqrt(fan_in)`` for weights (the scale of
+    torch's default init), GroupNorm gamma around 1, biases small.  ``salt`` shifts the phase.
+    """
+    out: Params = {}
+    for idx, (name, shape) in enumerate(param_shapes(in_ch, out_ch, base).items()):
+        n = 1
+        for s in shape:
+            n *= s
+        k = torch.arange(n, dtype=torch.float64)
+        phase = 0.37 * idx + 0.11 * salt
+        wave = torch.sin(k * 0.7 + phase) + 0.5 * torch.cos(k * 0.013 + 2.0 * phase)
+        if len(shape) == 4:
+            fan_in = shape[1] * shape[2] * shape[3]
+            if ".up.weight" in name:           # ConvTranspose2d: [C_in, C_out, 2, 2]
+                fan_in = shape[0] * 4 / 4      # each output pixel sees C_in taps
+            val = wave / math.sqrt(max(fan_in, 1))
+        elif name.endswith("body.1.weight") or name.endswith("body.4.weight"):
+            val = 1.0 + 0.1 * wave
+        else:
+            val = 0.05 * wave
+        out[name] = val.reshape(shape).to(dtype)
+    return out

@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures by running the REAL reference modules.
+
+Runs only in the authoring container (needs /root/reference).  The reference's pure-torch model files are
+imported under a synthetic package name so that ``src/__init__.py`` (which pulls omegaconf) is skipped
+(SURVEY.md section 8c).  Outputs: small ``.npz`` files next to this script (data only: inputs + expected outputs).
+
+    python tests/golden/gen_golden.py
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402  (only for closed_form_params / param_shapes: RNG-free weights)
+
+REF_SRC = "/root/reference/src"
+
+
+def load_reference():
+    pkg = types.ModuleType("refsrc")
+    pkg.__path__ = [REF_SRC]
+    sys.modules["refsrc"] = pkg
+    m = importlib.import_module("refsrc.unet_convlstm_attention")
+    u = importlib.import_module("refsrc.unet")
+    c = importlib.import_module("refsrc.convlstm")
+    return m, u, c
+
+
+def det_tensor(shape, salt, scale=1.0):
+    n = int(np.prod(shape))
+    k = torch.arange(n, dtype=torch.float64)
+    v = torch.sin(k * 0.37 + salt) + 0.6 * torch.cos(k * 0.0113 + 1.7 * salt) + 0.3 * torch.sin(k * 1.93 + 0.3 * salt)
+    return (scale * v).reshape(shape).float()
+
+
+def npz(name, **arrs):
+    out = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrs.items()}
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **out)
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(out)} arrays")
+
+
+def grads_of(module, prefix="g."):
+    return {prefix + k: p.grad for k, p in module.named_parameters() if p.grad is not None}
+
+
+def main():
+    torch.set_num_threads(8)
+    torch.manual_seed(0)
+    m, u, c = load_reference()
+
+    # ---------------------------------------------------------------- SEBlock
+    se = u.SEBlock(16)
+    with torch.no_grad():
+        se.fc[0].weight.copy_(det_tensor(se.fc[0].weight.shape, 1.0, 0.25))
+        se.fc[2].weight.copy_(det_tensor(se.fc[2].weight.shape, 2.0, 0.7))
+    x = det_tensor((3, 16, 6, 10), 3.0).requires_grad_()
+    dy = det_tensor((3, 16, 6, 10), 4.0)
+    y = se(x); y.backward(dy)
+    npz("se_block.npz", x=x, dy=dy, w1=se.fc[0].weight, w2=se.fc[2].weight, y=y, dx=x.grad,
+        dw1=se.fc[0].weight.grad, dw2=se.fc[2].weight.grad)
+
+    # ---------------------------------------------------------------- SpatialGate (+ tie case)
+    sg = u.SpatialGate()
+    with torch.no_grad():
+        sg.conv.weight.copy_(det_tensor(sg.conv.weight.shape, 5.0, 0.1))
+    x = det_tensor((2, 8, 8, 12), 6.0)
+    x[1, :, 2:5, 3:9] = 0.25          # all channels equal on a patch -> amax ties split 1/C
+    x[0, :4, 0, 0] = 9.0              # 4-way tie at one pixel
+    x = x.requires_grad_()
+    dy = det_tensor((2, 8, 8, 12), 7.0)
+    y = sg(x); y.backward(dy)
+    npz("spatial_gate.npz", x=x, dy=dy, w7=sg.conv.weight, y=y, dx=x.grad, dw7=sg.conv.weight.grad)
+
+    # ---------------------------------------------------------------- MaxPool2d(2) incl. ties
+    x = det_tensor((2, 4, 8, 12), 8.0)
+    x[0, 0, :4, :4] = 1.5             # all-equal windows -> grad to first element in scan order
+    x[1, 2] = 0.0
+    x = x.requires_grad_()
+    dy = det_tensor((2, 4, 4, 6), 9.0)
+    y = F.max_pool2d(x, 2); y.backward(dy)
+    npz("maxpool.npz", x=x, dy=dy, y=y, dx=x.grad)
+
+    # ---------------------------------------------------------------- ConvBlock 5 -> 16 @ 16x24
+    cb = u.ConvBlock(5, 16)
+    with torch.no_grad():
+        for i, p in enumerate(cb.parameters()):
+            if p.dim() == 4:
+                fan = p.shape[1] * p.shape[2] * p.shape[3]
+                p.copy_(det_tensor(p.shape, 10.0 + i, 1.0 / np.sqrt(fan)))
+            else:
+                p.copy_((1.0 if i in (1, 4) else 0.0) + det_tensor(p.shape, 10.0 + i, 0.1))
+    x = det_tensor((3, 5, 16, 24), 20.0).requires_grad_()
+    dy = det_tensor((3, 16, 16, 24), 21.0)
+    y = cb(x); y.backward(dy)
+    npz("conv_block.npz", x=x, dy=dy, y=y, dx=x.grad, **{"p." + k: v for k, v in cb.state_dict().items()},
+        **grads_of(cb))
+
+    # ---------------------------------------------------------------- Up 32(+32 skip) -> 16 @ 6x9 -> 12x18
+    up = u.Up(32, 32, 16)
+    with torch.no_grad():
+        for i, (k, p) in enumerate(up.named_parameters()):
+            if p.dim() == 4:
+                fan = p.shape[1] * p.shape[2] * p.shape[3] if "up.weight" not in k else p.shape[0]
+                p.copy_(det_tensor(p.shape, 30.0 + i, 1.0 / np.sqrt(fan)))
+            elif k.endswith("body.1.weight") or k.endswith("body.4.weight"):
+                p.copy_(1.0 + det_tensor(p.shape, 30.0 + i, 0.1))
+            else:
+                p.copy_(det_tensor(p.shape, 30.0 + i, 0.1))
+    x = det_tensor((2, 32, 6, 9), 40.0).requires_grad_()
+    sk = det_tensor((2, 32, 12, 18), 41.0).requires_grad_()
+    dy = det_tensor((2, 16, 12, 18), 42.0)
+    y = up(x, sk); y.backward(dy)
+    npz("up_block.npz", x=x, skip=sk, dy=dy, y=y, dx=x.grad, dskip=sk.grad,
+        **{"p." + k: v for k, v in up.state_dict().items()}, **grads_of(up))
+
+    # ---------------------------------------------------------------- ConvLSTM c_in=16, c_hid=8, T=3 @ 6x9
+    cl = c.ConvLSTM(16, 8)
+    with torch.no_grad():
+        cl.cell.conv.weight.copy_(det_tensor(cl.cell.conv.weight.shape, 50.0, 1.0 / np.sqrt(24 * 9)))
+        cl.cell.conv.bias.copy_(det_tensor(cl.cell.conv.bias.shape, 51.0, 0.1))
+    xs = det_tensor((3, 2, 16, 6, 9), 52.0).requires_grad_()
+    dy = det_tensor((3, 2, 8, 6, 9), 53.0)
+    dy[:2] = 0.0                       # the model only consumes the last hidden state
+    hs = cl(xs); hs.backward(dy)
+    npz("convlstm.npz", x_seq=xs, dy=dy, h_seq=hs, dx_seq=xs.grad, w=cl.cell.conv.weight, b=cl.cell.conv.bias,
+        dw=cl.cell.conv.weight.grad, db=cl.cell.conv.bias.grad)
+    # all time steps receive gradient (generic BPTT)
+    xs2 = xs.detach().clone().requires_grad_()
+    cl.zero_grad()
+    dy2 = det_tensor((3, 2, 8, 6, 9), 54.0)
+    hs2 = cl(xs2); hs2.backward(dy2)
+    npz("convlstm_alldy.npz", x_seq=xs2, dy=dy2, h_seq=hs2, dx_seq=xs2.grad, w=cl.cell.conv.weight,
+        b=cl.cell.conv.bias, dw=cl.cell.conv.weight.grad, db=cl.cell.conv.bias.grad)
+
+    # ---------------------------------------------------------------- whole model, tiny
+    in_ch, out_ch, base, T, B, H, W = 5, 2, 8, 3, 2, 16, 24
+    params = oracle.closed_form_params(in_ch, out_ch, base)
+    net = m.AttUNetConvLSTM(in_ch=in_ch, out_ch=out_ch, base=base, seq_len=T)
+    net.load_state_dict(params)
+    x = det_tensor((B, T, in_ch, H, W), 60.0)
+    x[0, :2] = 0.0                     # left zero-padded window (main_final.py:127-131)
+    yt = det_tensor((B, out_ch, H, W), 61.0)
+    opt = torch.optim.Adam(net.parameters(), lr=5e-4, weight_decay=0)
+    arrs = dict(x=x, y=yt, cfg=np.array([in_ch, out_ch, base, T, B, H, W]))
+    xg = x.clone().requires_grad_()
+    for step in range(1, 4):
+        opt.zero_grad()
+        pred = net(xg if step == 1 else x)
+        loss = F.mse_loss(pred, yt)
+        loss.backward()
+        if step == 1:
+            arrs["pred"] = pred
+            arrs["dx"] = xg.grad
+            for k, p in net.named_parameters():
+                if p.grad is not None:
+                    arrs["g." + k] = p.grad.clone()
+            arrs["nograd"] = np.array([k for k, p in net.named_parameters() if p.grad is None])
+        arrs[f"loss{step}"] = loss
+        opt.step()
+        if step in (1, 3):
+            for k, v in net.state_dict().items():
+                arrs[f"p{step}." + k] = v.clone()
+    npz("model_tiny.npz", **arrs)
+
+    # ---------------------------------------------------------------- second tiny config: base=16, T=2, odd-ish grid
+    in_ch, out_ch, base, T, B, H, W = 5, 2, 16, 2, 3, 8, 16
+    params = oracle.closed_form_params(in_ch, out_ch, base, salt=3)
+    net = m.AttUNetConvLSTM(in_ch=in_ch, out_ch=out_ch, base=base, seq_len=T)
+    net.load_state_dict(params)
+    x = det_tensor((B, T, in_ch, H, W), 62.0).requires_grad_()
+    yt = det_tensor((B, out_ch, H, W), 63.0)
+    pred = net(x); loss = F.mse_loss(pred, yt); loss.backward()
+    arrs = dict(x=x, y=yt, cfg=np.array([in_ch, out_ch, base, T, B, H, W]), salt=np.array(3), pred=pred, loss1=loss,
+                dx=x.grad)
+    for k, p in net.named_parameters():
+        if p.grad is not None:
+            arrs["g." + k] = p.grad.clone()
+    npz("model_tiny_b16.npz", **arrs)
+
+    # ---------------------------------------------------------------- BASELINE config 2 shape: checksums only
+    in_ch, out_ch, base, T, B, H, W = 5, 2, 32, 6, 32, 48, 72
+    params = oracle.closed_form_params(in_ch, out_ch, base)
+    net = m.AttUNetConvLSTM(in_ch=in_ch, out_ch=out_ch, base=base, seq_len=T)
+    net.load_state_dict(params)
+    g = torch.Generator("cpu").manual_seed(1234)
+    x = torch.randn(B, T, in_ch, H, W, generator=g)
+    yt = torch.randn(B, out_ch, H, W, generator=g)
+    pred = net(x); loss = F.mse_loss(pred, yt); loss.backward()
+    idx = torch.linspace(0, pred.numel() - 1, 64).long()
+    arrs = dict(cfg=np.array([in_ch, out_ch, base, T, B, H, W]), seed=np.array(1234), loss=loss,
+                pred_l2=pred.double().norm(), pred_samples=pred.flatten()[idx], pred_sample_idx=idx,
+                x_l2=x.double().norm(), y_l2=yt.double().norm())
+    names, norms, samples = [], [], []
+    for k, p in net.named_parameters():
+        if p.grad is None:
+            continue
+        names.append(k); norms.append(p.grad.double().norm().item())
+        ii = torch.linspace(0, p.numel() - 1, 8).long()
+        samples.append(p.grad.flatten()[ii].numpy())
+    arrs.update(grad_names=np.array(names), grad_l2=np.array(norms), grad_samples=np.stack(samples))
+    npz("cfg2_checksums.npz", **arrs)
+
+    # ---------------------------------------------------------------- default-init parity under a seed
+    torch.manual_seed(42)              # configs/main_config.yaml:11
+    net = m.AttUNetConvLSTM(in_ch=5, out_ch=2, base=32, seq_len=6)
+    names, sums, firsts = [], [], []
+    for k, v in net.state_dict().items():
+        names.append(k); sums.append(v.double().sum().item()); firsts.append(v.flatten()[:4].double().numpy())
+    npz("init_seed42_base32.npz", names=np.array(names), sums=np.array(sums),
+        firsts=np.stack([np.pad(f, (0, 4 - len(f))) for f in firsts]))
+
+
+if __name__ == "__main__":
+    main()
