@@ -1,0 +1,143 @@
+/* climate_hip.h -- C ABI of libclimate_hip.so: the MI355X (gfx950) hot path of the unet_convlstm_attention
+ * climate emulator.
+ *
+ * The reference (ZhenmanShen/Physics-Based-Climate-Model) has no FFI: its seam is Python
+ * (src/models.py:7-38 get_model -> nn.Module.forward, main_final.py:538-561,737-747 LightningModule).  This header is
+ * the native boundary underneath that seam: plain pointers, sizes and a HIP stream handle; no torch types.
+ * Each entry cites the reference call site(s) (paths relative to the reference root) that it replaces.
+ *
+ * Conventions
+ *  - all tensors fp32, NCHW, channel stride == H*W, rows contiguous;
+ *  - every tensor pointer is followed (where it can be a slice) by its per-sample stride in ELEMENTS;
+ *  - `stream` is a hipStream_t passed as void*; every call only enqueues work on it (graph-capture safe: no
+ *    allocation, no synchronisation);
+ *  - return value 0 = ok, negative = -errno style argument error, positive = hipError_t.
+ */
+#ifndef CLIMATE_HIP_H
+#define CLIMATE_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* cm_stream;
+
+/* ---- library ---------------------------------------------------------------------------------------------- */
+int cm_version(void);                 /* ABI version, bumped on any signature change */
+const char* cm_arch(void);            /* "gfx950" */
+
+/* ---- conv3x3 (implicit GEMM on fp32 MFMA) ------------------------------------------------------------------ *
+ * nn.Conv2d(ci, co, 3, padding=1): src/unet.py:36,38; gate conv src/convlstm.py:9,13; its data gradient.         */
+int cm_conv3x3_num_configs(void);
+int cm_conv3x3_pick_config(int n, int h, int w, int cout);
+long long cm_conv3x3_packed_elems(int k_channels, int out_channels);
+/* w: [cout][cin_total][3][3]; packs input-channel range [c_off, c_off+cin).
+ * dgrad=0: operand for y = conv(x, w).  dgrad=1: operand for dx = conv(dy, flip/transposed w). */
+int cm_pack_conv3x3(const float* w, int cout, int cin_total, int c_off, int cin, int dgrad, float* wp,
+                    cm_stream stream);
+/* out[n, :cout] = conv3x3(cat(in0[:, :c0], in1[:, :c1]), wp) (+ bias) (+ resid).  in1 may be NULL (c1 = 0).
+ * resid (nullable) uses the addressing of out (st_resid must equal st_out; resid may alias out).
+ * config < 0 picks a tile configuration automatically. */
+int cm_conv3x3(const float* in0, long long st0, int c0, const float* in1, long long st1, int c1, const float* wp,
+               const float* bias, const float* resid, long long st_resid, float* out, long long st_out, int n, int h,
+               int w, int cout, int config, cm_stream stream);
+
+/* ---- conv3x3 weight gradient ------------------------------------------------------------------------------- *
+ * convolution_backward (weight) of the convs above.  Accumulates (fp32 atomics) into a tap-major staging buffer
+ * g[cout][9][ctot] that the caller zeroes once per step; cm_wgrad3x3_unpack transposes it to [cout][ctot][3][3].
+ * x = cat(x0[:, :c0], x1[:, :c1]) occupies input-channel range [c_off, c_off+c0+c1) of the full weight.          */
+int cm_wgrad3x3_num_configs(void);
+int cm_wgrad3x3_pick_config(int n, int h, int w, int cout);
+int cm_wgrad3x3(const float* x0, long long sx0, int c0, const float* x1, long long sx1, int c1, const float* dy,
+                long long sdy, float* g, int ctot, int c_off, int n, int h, int w, int cout, int config,
+                cm_stream stream);
+int cm_wgrad3x3_unpack(const float* g, float* dw, int cout, int ctot, float scale, cm_stream stream);
+
+/* ---- GroupNorm(8) + SiLU ----------------------------------------------------------------------------------- *
+ * nn.GroupNorm(8, c), nn.SiLU: src/unet.py:37,39.  stats[n*groups+g] = {mean, rstd}.  pooled (nullable) receives
+ * mean_hw(y) per (n,c) = SEBlock's AdaptiveAvgPool2d(1) (src/unet.py:10).  x, y, dx are contiguous [n,c,hw].     */
+int cm_gn_silu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, float* pooled,
+                   int n, int c, int hw, int groups, float eps, cm_stream stream);
+/* dA = gradient wrt y (sample stride st_dA); dgamma/dbeta are ACCUMULATED (atomics). */
+int cm_gn_silu_bwd(const float* x, const float* gamma, const float* beta, const float* stats, const float* dA,
+                   long long st_dA, float* dx, float* dgamma, float* dbeta, int n, int c, int hw, int groups,
+                   cm_stream stream);
+/* same, with the gradient wrt y rebuilt on the fly from the SE / spatial-gate backward maps (see below). */
+int cm_gn_silu_bwd_gated(const float* x, const float* gamma, const float* beta, const float* stats,
+                         const float* a2, const float* dout, const float* gate, const float* dmap, const float* fmap,
+                         const float* cnt, const float* s, const float* dpool, float* dx, float* dgamma,
+                         float* dbeta, int n, int c, int hw, int groups, cm_stream stream);
+
+/* ---- SE channel gate + CBAM spatial gate ------------------------------------------------------------------- *
+ * SEBlock src/unet.py:6-17, SpatialGate src/unet.py:19-29.  a2 [n,c,hw] = activation entering SE; s [n,c] SE scale;
+ * z [n,cr] = W1 pooled (pre-ReLU); map [n,2,hw] = [mean_c, max_c](a2*s); gate [n,hw]; out = a2*s*gate.           */
+int cm_se_excite_fwd(const float* pooled, const float* w1, const float* w2, float* z, float* s, int n, int c, int cr,
+                     cm_stream stream);
+int cm_spatial_stats(const float* a2, const float* s, float* map, int n, int c, int hw, cm_stream stream);
+int cm_spatial_apply(const float* a2, const float* s, const float* map, const float* w7, float* gate, float* out,
+                     int n, int c, int h, int w, cm_stream stream);
+/* backward chain: gate_bwd_reduce -> conv7_bwd -> se_bwd_reduce -> se_excite_bwd -> cm_gn_silu_bwd_gated */
+int cm_gate_bwd_reduce(const float* dout, const float* a2, const float* s, const float* gate, const float* map,
+                       float* dgpre, float* cnt, int n, int c, int hw, cm_stream stream);
+int cm_conv7_bwd(const float* dgpre, const float* map, const float* w7, float* dmap, float* dw7 /* accumulated */,
+                 int n, int h, int w, cm_stream stream);
+int cm_se_bwd_reduce(const float* dout, const float* a2, const float* s, const float* gate, const float* dmap,
+                     const float* map, const float* cnt, float* ds, int n, int c, int hw, cm_stream stream);
+/* dsig [n,c], dz [n,cr], dpool [n,c] are outputs; dw1 [cr,c], dw2 [c,cr] are ACCUMULATED. */
+int cm_se_excite_bwd(const float* ds, const float* s, const float* z, const float* pooled, const float* w1,
+                     const float* w2, float* dsig, float* dz, float* dpool, float* dw1, float* dw2, int n, int c,
+                     int cr, cm_stream stream);
+
+/* ---- MaxPool2d(2), time-mean skips, per-channel sums ------------------------------------------------------- *
+ * nn.MaxPool2d(2): src/unet_convlstm_attention.py:21,25.  stack(...).mean(0): src/unet_convlstm_attention.py:91-93. */
+int cm_maxpool2_fwd(const float* x, float* y, long long planes, int h, int w, cm_stream stream);
+/* dx = maxpool_backward(dy) + scale * dskip[n / t] (dskip nullable; [n/t, c, h, w] with sample stride st_dskip) */
+int cm_maxpool2_bwd(const float* x, const float* dy, const float* dskip, long long st_dskip, float* dx, int n, int c,
+                    int h, int w, int t, float scale, cm_stream stream);
+int cm_time_mean(const float* x, float* y, int b, int t, long long chw, cm_stream stream);
+/* out[c] += sum_{n,p} x[n,c,p]  (bias gradients) */
+int cm_channel_sum(const float* x, long long st, float* out, int n, int c, int hw, cm_stream stream);
+
+/* ---- ConvTranspose2d(2, stride 2) -------------------------------------------------------------------------- *
+ * nn.ConvTranspose2d(ci, co, 2, stride=2): src/unet.py:63,67.  w: [ci][co][2][2]; x [n,ci,h,w] -> y [n,co,2h,2w]. */
+int cm_convT2x2_fwd(const float* x, long long sx, const float* w, const float* b, float* y, long long sy, int n,
+                    int ci, int co, int h, int w_, cm_stream stream);
+int cm_convT2x2_bwd_data(const float* dy, long long sdy, const float* w, float* dx, long long sdx, int n, int ci,
+                         int co, int h, int w_, cm_stream stream);
+int cm_convT2x2_bwd_weight(const float* x, long long sx, const float* dy, long long sdy, float* dw /* accumulated */,
+                           int n, int ci, int co, int h, int w_, cm_stream stream);
+
+/* ---- ConvLSTM cell pointwise stage ------------------------------------------------------------------------- *
+ * ConvLSTMCell.forward src/convlstm.py:14-19 (gate order i,f,o,g).  gates [b,4ch,hw]: pre-activations in,
+ * activations out (forward); activations in, d(pre-activations) out (backward).  c_prev nullable (= 0).          */
+int cm_lstm_gates_fwd(float* gates, long long sg, const float* c_prev, long long scp, float* c_out, long long sco,
+                      float* h_out, long long sho, int b, int ch, int hw, cm_stream stream);
+/* dh = dh_a + dh_b (either nullable); dc [b,ch,hw] contiguous: in dL/dc_t (ignored if first), out dL/dc_{t-1}.   */
+int cm_lstm_gates_bwd(float* gates, long long sg, const float* c_prev, long long scp, const float* c_cur,
+                      long long scc, const float* dh_a, long long sa, const float* dh_b, long long sb, float* dc,
+                      int first, int b, int ch, int hw, cm_stream stream);
+
+/* ---- head + loss ------------------------------------------------------------------------------------------- *
+ * nn.Conv2d(base, out_ch, 1): src/unet_convlstm_attention.py:56,104.  nn.MSELoss(): main_final.py:544,559.       */
+int cm_head_fwd(const float* x, long long sx, const float* w, const float* b, float* pred, int n, int c, int oc,
+                int hw, cm_stream stream);
+/* *loss = mean((pred-y)^2) (zeroed inside); dpred (nullable) = 2 (pred-y) / total */
+int cm_mse_loss(const float* pred, const float* y, float* loss, float* dpred, long long total, cm_stream stream);
+/* dw [oc,c], db [oc] ACCUMULATED */
+int cm_head_bwd(const float* dpred, const float* x, long long sx, const float* w, float* dx, long long sdx, float* dw,
+                float* db, int n, int c, int oc, int hw, cm_stream stream);
+
+/* ---- optimizer --------------------------------------------------------------------------------------------- *
+ * optim.Adam: main_final.py:742-746 (torch defaults).  Flat, 16-byte aligned buffers.  grad_scale multiplies g.  */
+int cm_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                 float eps, float weight_decay, int step, float grad_scale, cm_stream stream);
+/* graph-replay safe: the step counter and bias corrections live in state[4] on the device and advance per call */
+int cm_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, float* state, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, float grad_scale, cm_stream stream);
+int cm_scale(float* x, long long n, float s, cm_stream stream);
+int cm_zero(void* p, size_t bytes, cm_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLIMATE_HIP_H */

@@ -1,0 +1,345 @@
+// SE channel gate + CBAM spatial gate of ConvBlock: forward and backward.
+//
+// Reference: SEBlock (src/unet.py:6-17): x * sigmoid(W2 relu(W1 mean_hw x)), bias-free 1x1 convs, r = 8.
+//            SpatialGate (src/unet.py:19-29): x * sigmoid(conv7x7(cat[mean_c x, amax_c x])), pad 3, no bias.
+// Notation: a2 = activation entering SE, s = SE scale [N,C], U = a2*s, map = [mean_c U, max_c U], gate = sigmoid(conv7(map)),
+// out = U*gate.  The squeeze (mean_hw a2) is produced by the GroupNorm kernel (norm_act.hip).
+//
+// Backward facts pinned by the golden fixtures: amax splits its gradient EQUALLY among tied channels (so the tie
+// count map `cnt` is built from the bit-exact product a2*s), mean_c spreads 1/C.
+#include "common.h"
+#include "../../include/climate_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ SE excite
+// one workgroup per sample: z = W1 p (Cr), s = sigmoid(W2 relu(z)) (C)
+__global__ __launch_bounds__(256) void se_excite_fwd_kernel(const float* __restrict__ pooled,
+                                                             const float* __restrict__ w1,
+                                                             const float* __restrict__ w2, float* __restrict__ z,
+                                                             float* __restrict__ s, int C, int Cr) {
+  extern __shared__ float sh[];  // [C] pooled + [Cr] hidden
+  float* p = sh;
+  float* hsh = sh + C;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  for (int c = tid; c < C; c += blockDim.x) p[c] = pooled[(long long)n * C + c];
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  for (int r = wave; r < Cr; r += nw) {
+    float a = 0.f;
+    for (int c = lane; c < C; c += 64) a += w1[(long long)r * C + c] * p[c];
+    a = wave_sum(a);
+    if (lane == 0) {
+      z[(long long)n * Cr + r] = a;
+      hsh[r] = fmaxf(a, 0.f);
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += blockDim.x) {
+    float a = 0.f;
+    for (int r = 0; r < Cr; ++r) a += w2[(long long)c * Cr + r] * hsh[r];
+    s[(long long)n * C + c] = sigmoid_acc(a);
+  }
+}
+
+// per sample: dsig = ds*s*(1-s); dh = W2^T dsig; dz = dh * 1[z>0]; dpool = W1^T dz
+__global__ __launch_bounds__(256) void se_excite_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ s,
+                                                             const float* __restrict__ z,
+                                                             const float* __restrict__ w1,
+                                                             const float* __restrict__ w2, float* __restrict__ dsig,
+                                                             float* __restrict__ dz, float* __restrict__ dpool, int C,
+                                                             int Cr) {
+  extern __shared__ float sh[];  // [C] dsig + [Cr] dz
+  float* dsg = sh;
+  float* dzs = sh + C;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  for (int c = tid; c < C; c += blockDim.x) {
+    const float sv = s[(long long)n * C + c];
+    const float v = ds[(long long)n * C + c] * sv * (1.f - sv);
+    dsg[c] = v;
+    dsig[(long long)n * C + c] = v;
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  for (int r = wave; r < Cr; r += nw) {
+    float a = 0.f;
+    for (int c = lane; c < C; c += 64) a += w2[(long long)c * Cr + r] * dsg[c];
+    a = wave_sum(a);
+    if (lane == 0) {
+      const float v = z[(long long)n * Cr + r] > 0.f ? a : 0.f;
+      dzs[r] = v;
+      dz[(long long)n * Cr + r] = v;
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += blockDim.x) {
+    float a = 0.f;
+    for (int r = 0; r < Cr; ++r) a += w1[(long long)r * C + c] * dzs[r];
+    dpool[(long long)n * C + c] = a;
+  }
+}
+
+// dW2[c][r] += sum_n dsig[n,c] relu(z[n,r]);  dW1[r][c] += sum_n dz[n,r] pooled[n,c]   (deterministic: one thread
+// per weight, serial over n)
+__global__ void se_wgrad_kernel(const float* __restrict__ dsig, const float* __restrict__ dz,
+                                const float* __restrict__ z, const float* __restrict__ pooled,
+                                float* __restrict__ dw1, float* __restrict__ dw2, int N, int C, int Cr) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * C * Cr) return;
+  if (i < C * Cr) {  // dW2[c][r]
+    const int c = i / Cr, r = i % Cr;
+    float a = 0.f;
+    for (int n = 0; n < N; ++n) a += dsig[(long long)n * C + c] * fmaxf(z[(long long)n * Cr + r], 0.f);
+    dw2[i] += a;
+  } else {           // dW1[r][c]
+    const int j = i - C * Cr;
+    const int r = j / C, c = j % C;
+    float a = 0.f;
+    for (int n = 0; n < N; ++n) a += dz[(long long)n * Cr + r] * pooled[(long long)n * C + c];
+    dw1[j] += a;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ spatial gate fwd
+// map[n,0,p] = mean_c(a2*s), map[n,1,p] = max_c(a2*s); one thread per pixel, coalesced along HW
+__global__ void spatial_stats_kernel(const float* __restrict__ a2, const float* __restrict__ s,
+                                     float* __restrict__ map, int C, int HW) {
+  const int n = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= HW) return;
+  const float* ap = a2 + (long long)n * C * HW + p;
+  const float* sp = s + (long long)n * C;
+  float sum = 0.f, mx = -INFINITY;
+  for (int c = 0; c < C; ++c) {
+    const float u = ap[(long long)c * HW] * sp[c];
+    sum += u;
+    mx = fmaxf(mx, u);
+  }
+  map[((long long)n * 2) * HW + p] = sum / (float)C;
+  map[((long long)n * 2 + 1) * HW + p] = mx;
+}
+
+__device__ __forceinline__ float conv7_at(const float* __restrict__ mp, const float* __restrict__ w7, int y, int x,
+                                          int H, int W) {
+  float a = 0.f;
+  const int HW = H * W;
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch)
+    for (int dy = 0; dy < 7; ++dy) {
+      const int yy = y + dy - 3;
+      if (yy < 0 || yy >= H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 7; ++dx) {
+        const int xx = x + dx - 3;
+        if (xx >= 0 && xx < W) a += w7[ch * 49 + dy * 7 + dx] * mp[ch * HW + yy * W + xx];
+      }
+    }
+  return a;
+}
+
+// gate = sigmoid(conv7x7(map)); out = a2 * s * gate.  grid = (pixel blocks, N, channel splits)
+__global__ void spatial_apply_kernel(const float* __restrict__ a2, const float* __restrict__ s,
+                                     const float* __restrict__ map, const float* __restrict__ w7,
+                                     float* __restrict__ gate, float* __restrict__ out, int C, int H, int W,
+                                     int c_per_split) {
+  __shared__ float wsh[98];
+  if (threadIdx.x < 98) wsh[threadIdx.x] = w7[threadIdx.x];
+  __syncthreads();
+  const int HW = H * W;
+  const int n = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= HW) return;
+  const float gpre = conv7_at(map + (long long)n * 2 * HW, wsh, p / W, p % W, H, W);
+  const float g = sigmoid_acc(gpre);
+  if (blockIdx.z == 0) gate[(long long)n * HW + p] = g;
+  const int c0 = blockIdx.z * c_per_split;
+  const int c1 = min(C, c0 + c_per_split);
+  const float* sp = s + (long long)n * C;
+  for (int c = c0; c < c1; ++c) {
+    const long long i = ((long long)n * C + c) * HW + p;
+    out[i] = (a2[i] * sp[c]) * g;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ spatial gate bwd
+// per pixel: dgate = sum_c dout*U; dgpre = dgate*gate*(1-gate); cnt = #{c: U == max}
+__global__ void gate_bwd_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ a2,
+                                       const float* __restrict__ s, const float* __restrict__ gate,
+                                       const float* __restrict__ map, float* __restrict__ dgpre,
+                                       float* __restrict__ cnt, int C, int HW) {
+  const int n = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= HW) return;
+  const float mx = map[((long long)n * 2 + 1) * HW + p];
+  const float* sp = s + (long long)n * C;
+  float dg = 0.f, k = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const long long i = ((long long)n * C + c) * HW + p;
+    const float u = a2[i] * sp[c];
+    dg += dout[i] * u;
+    k += (u == mx) ? 1.f : 0.f;
+  }
+  const float g = gate[(long long)n * HW + p];
+  dgpre[(long long)n * HW + p] = dg * g * (1.f - g);
+  cnt[(long long)n * HW + p] = k;
+}
+
+// dmap[n,ch,p] = sum_taps dgpre[n, p - (tap-3)] * w7[ch][tap];  dW7[ch][tap] += sum_{n,p} map[n,ch,p+tap-3]*dgpre[n,p]
+// one workgroup per (row band, sample); the band's dgpre rows (+-3) and map rows (+-3) are staged in LDS
+template <int BAND>
+__global__ __launch_bounds__(256) void conv7_bwd_kernel(const float* __restrict__ dgpre,
+                                                         const float* __restrict__ map,
+                                                         const float* __restrict__ w7, float* __restrict__ dmap,
+                                                         float* __restrict__ dw7, int H, int W) {
+  extern __shared__ float sh[];
+  const int PW = W + 6;
+  float* dsh = sh;                          // [(BAND+6)][PW]  dgpre rows y0-3 .. y0+BAND+2, zero padded
+  float* msh = sh + (BAND + 6) * PW;        // [2][(BAND+6)][PW] map rows, zero padded
+  __shared__ float wsh[98];
+  const int n = blockIdx.y, y0 = blockIdx.x * BAND, HW = H * W, tid = threadIdx.x;
+  if (tid < 98) wsh[tid] = w7[tid];
+  const int plane = (BAND + 6) * PW;
+  for (int i = tid; i < 3 * plane; i += 256) {
+    const int which = i / plane, r = (i % plane) / PW, cpos = (i % plane) % PW;
+    const int yy = y0 - 3 + r, xx = cpos - 3;
+    float v = 0.f;
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+      v = which == 0 ? dgpre[(long long)n * HW + yy * W + xx]
+                     : map[((long long)n * 2 + (which - 1)) * HW + yy * W + xx];
+    }
+    sh[i] = v;
+  }
+  __syncthreads();
+  // dmap for the band's pixels (flipped kernel)
+  for (int i = tid; i < 2 * BAND * W; i += 256) {
+    const int ch = i / (BAND * W), r = (i % (BAND * W)) / W, x = i % W;
+    if (y0 + r >= H) continue;
+    float a = 0.f;
+    for (int dy = 0; dy < 7; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 7; ++dx) a += wsh[ch * 49 + dy * 7 + dx] * dsh[(r + 6 - dy) * PW + (x + 6 - dx)];
+    dmap[((long long)n * 2 + ch) * HW + (y0 + r) * W + x] = a;
+  }
+  // weight gradient: thread t < 98 owns one tap and walks the band's pixels
+  if (tid < 98) {
+    const int ch = tid / 49, dy = (tid % 49) / 7, dx = tid % 7;
+    const float* mp = msh + ch * plane;
+    float a = 0.f;
+    for (int r = 0; r < BAND; ++r)
+      for (int x = 0; x < W; ++x) a += mp[(r + dy) * PW + (x + dx)] * dsh[(r + 3) * PW + (x + 3)];
+    unsafeAtomicAdd(dw7 + tid, a);
+  }
+}
+
+// ds[n,c] = sum_p dU * a2, with dU = dout*gate + dmapA/C + dmapM*[U==max]/cnt.  One wave per (n,c).
+__global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const float* __restrict__ dout,
+                                                             const float* __restrict__ a2,
+                                                             const float* __restrict__ s,
+                                                             const float* __restrict__ gate,
+                                                             const float* __restrict__ dmap,
+                                                             const float* __restrict__ map,
+                                                             const float* __restrict__ cnt, float* __restrict__ ds,
+                                                             int NC, int C, int HW) {
+  const int lane = threadIdx.x & 63;
+  const int nc = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (nc >= NC) return;
+  const int n = nc / C;
+  const float sc = s[nc];
+  const float inv_c = 1.f / (float)C;
+  const float* gp = gate + (long long)n * HW;
+  const float* da = dmap + (long long)n * 2 * HW;
+  const float* dm = da + HW;
+  const float* mx = map + ((long long)n * 2 + 1) * HW;
+  const float* ct = cnt + (long long)n * HW;
+  const float* dop = dout + (long long)nc * HW;
+  const float* ap = a2 + (long long)nc * HW;
+  float acc = 0.f;
+  for (int p = lane; p < HW; p += 64) {
+    const float a = ap[p];
+    const float u = a * sc;
+    float dU = dop[p] * gp[p] + da[p] * inv_c;
+    if (u == mx[p]) dU += dm[p] / ct[p];
+    acc += dU * a;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) ds[nc] = acc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cm_se_excite_fwd(const float* pooled, const float* w1, const float* w2, float* z, float* s, int n, int c, int cr,
+                     cm_stream stream) {
+  if (n <= 0 || c <= 0 || cr <= 0) return -22;
+  se_excite_fwd_kernel<<<n, 256, (c + cr) * sizeof(float), (hipStream_t)stream>>>(pooled, w1, w2, z, s, c, cr);
+  CM_CHECK_LAUNCH();
+  return 0;
+}
+
+int cm_se_excite_bwd(const float* ds, const float* s, const float* z, const float* pooled, const float* w1,
+                     const float* w2, float* dsig, float* dz, float* dpool, float* dw1, float* dw2, int n, int c,
+                     int cr, cm_stream stream) {
+  if (n <= 0 || c <= 0 || cr <= 0) return -22;
+  se_excite_bwd_kernel<<<n, 256, (c + cr) * sizeof(float), (hipStream_t)stream>>>(ds, s, z, w1, w2, dsig, dz, dpool,
+                                                                                   c, cr);
+  CM_CHECK_LAUNCH();
+  se_wgrad_kernel<<<cdiv(2 * c * cr, 256), 256, 0, (hipStream_t)stream>>>(dsig, dz, z, pooled, dw1, dw2, n, c, cr);
+  CM_CHECK_LAUNCH();
+  return 0;
+}
+
+int cm_spatial_stats(const float* a2, const float* s, float* map, int n, int c, int hw, cm_stream stream) {
+  if (n <= 0 || c <= 0 || hw <= 0) return -22;
+  const int bs = hw >= 256 ? 256 : 64;
+  spatial_stats_kernel<<<dim3(cdiv(hw, bs), n), bs, 0, (hipStream_t)stream>>>(a2, s, map, c, hw);
+  CM_CHECK_LAUNCH();
+  return 0;
+}
+
+int cm_spatial_apply(const float* a2, const float* s, const float* map, const float* w7, float* gate, float* out,
+                     int n, int c, int h, int w, cm_stream stream) {
+  if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return -22;
+  const int hw = h * w;
+  const int bs = hw >= 256 ? 256 : 128;
+  const int pb = cdiv(hw, bs);
+  int splits = 1;
+  while ((long long)pb * n * splits < 1024 && splits * 8 <= c) splits *= 2;  // enough workgroups for 256 CUs
+  const int cps = cdiv(c, splits);
+  spatial_apply_kernel<<<dim3(pb, n, cdiv(c, cps)), bs, 0, (hipStream_t)stream>>>(a2, s, map, w7, gate, out, c, h, w,
+                                                                                  cps);
+  CM_CHECK_LAUNCH();
+  return 0;
+}
+
+int cm_gate_bwd_reduce(const float* dout, const float* a2, const float* s, const float* gate, const float* map,
+                       float* dgpre, float* cnt, int n, int c, int hw, cm_stream stream) {
+  if (n <= 0 || c <= 0 || hw <= 0) return -22;
+  const int bs = hw >= 256 ? 256 : 64;
+  gate_bwd_reduce_kernel<<<dim3(cdiv(hw, bs), n), bs, 0, (hipStream_t)stream>>>(dout, a2, s, gate, map, dgpre, cnt, c,
+                                                                                hw);
+  CM_CHECK_LAUNCH();
+  return 0;
+}
+
+int cm_conv7_bwd(const float* dgpre, const float* map, const float* w7, float* dmap, float* dw7, int n, int h, int w,
+                 cm_stream stream) {
+  if (n <= 0 || h <= 0 || w <= 0) return -22;
+  constexpr int BAND = 8;
+  const size_t lds = (size_t)3 * (BAND + 6) * (w + 6) * sizeof(float);
+  if (lds > 60 * 1024) return -22;  // W up to ~360
+  conv7_bwd_kernel<BAND><<<dim3(cdiv(h, BAND), n), 256, lds, (hipStream_t)stream>>>(dgpre, map, w7, dmap, dw7, h, w);
+  CM_CHECK_LAUNCH();
+  return 0;
+}
+
+int cm_se_bwd_reduce(const float* dout, const float* a2, const float* s, const float* gate, const float* dmap,
+                     const float* map, const float* cnt, float* ds, int n, int c, int hw, cm_stream stream) {
+  if (n <= 0 || c <= 0 || hw <= 0) return -22;
+  se_bwd_reduce_kernel<<<cdiv((long long)n * c, 4), 256, 0, (hipStream_t)stream>>>(dout, a2, s, gate, dmap, map, cnt,
+                                                                                   ds, n * c, c, hw);
+  CM_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

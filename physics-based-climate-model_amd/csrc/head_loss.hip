@@ -1,0 +1,126 @@
+// Output head (1x1 conv + bias), MSE loss, and their backward.
+//
+// Reference: self.head = nn.Conv2d(base, out_ch, 1) (src/unet_convlstm_attention.py:56,104); nn.MSELoss()
+// (main_final.py:544,559): loss = mean((pred - y)^2) over B*out_ch*H*W; d pred = 2 (pred - y) / N.
+#include "common.h"
+#include "../../include/climate_hip.h"
+
+namespace {
+
+constexpr int MAXOC = 8;
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, long long sx,
+                                                        const float* __restrict__ w, const float* __restrict__ b,
+                                                        float* __restrict__ pred, int C, int OC, int HW) {
+  const int n = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= HW) return;
+  float acc[MAXOC];
+#pragma unroll
+  for (int o = 0; o < MAXOC; ++o) acc[o] = (o < OC) ? b[o] : 0.f;
+  const float* xp = x + (long long)n * sx + p;
+  for (int c = 0; c < C; ++c) {
+    const float xv = xp[(long long)c * HW];
+#pragma unroll
+    for (int o = 0; o < MAXOC; ++o)
+      if (o < OC) acc[o] += w[o * C + c] * xv;
+  }
+#pragma unroll
+  for (int o = 0; o < MAXOC; ++o)
+    if (o < OC) pred[((long long)n * OC + o) * HW + p] = acc[o];
+}
+
+// loss += sum (pred-y)^2 / total ; dpred = 2 (pred - y) / total
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred, const float* __restrict__ y,
+                                                   float* __restrict__ loss, float* __restrict__ dpred,
+                                                   long long total) {
+  __shared__ float red[32];
+  const float inv = 1.f / (float)total;
+  float a = 0.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float d = pred[i] - y[i];
+    a += d * d;
+    if (dpred) dpred[i] = 2.f * d * inv;
+  }
+  a = block_sum(a, red);
+  if (threadIdx.x == 0) unsafeAtomicAdd(loss, a * inv);
+}
+
+// dx[n,c,p] = sum_o W[o][c] dpred[n,o,p]; dW[o][c] += sum_{n,p} dpred x; db[o] += sum dpred
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dpred, const float* __restrict__ x,
+                                                        long long sx, const float* __restrict__ w,
+                                                        float* __restrict__ dx, long long sdx,
+                                                        float* __restrict__ dw, float* __restrict__ db, int C,
+                                                        int OC, int HW, int tiles_per_block) {
+  extern __shared__ float sh[];  // [OC*C] dW partial + [OC] db partial
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int n = blockIdx.y;
+  for (int i = tid; i < OC * C + OC; i += 256) sh[i] = 0.f;
+  __syncthreads();
+  for (int tl = 0; tl < tiles_per_block; ++tl) {
+    const int p = (blockIdx.x * tiles_per_block + tl) * 256 + tid;
+    const bool ok = p < HW;
+    float dp[MAXOC];
+#pragma unroll
+    for (int o = 0; o < MAXOC; ++o) dp[o] = (ok && o < OC) ? dpred[((long long)n * OC + o) * HW + p] : 0.f;
+#pragma unroll
+    for (int o = 0; o < MAXOC; ++o) {
+      if (o < OC) {
+        const float s = wave_sum(dp[o]);
+        if (lane == 0) atomicAdd(&sh[OC * C + o], s);
+      }
+    }
+    for (int c = 0; c < C; ++c) {
+      const float xv = ok ? x[(long long)n * sx + (long long)c * HW + p] : 0.f;
+      float g = 0.f;
+#pragma unroll
+      for (int o = 0; o < MAXOC; ++o) {
+        if (o < OC) {
+          g += w[o * C + c] * dp[o];
+          const float s = wave_sum(dp[o] * xv);
+          if (lane == 0) atomicAdd(&sh[o * C + c], s);
+        }
+      }
+      if (ok) dx[(long long)n * sdx + (long long)c * HW + p] = g;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < OC * C; i += 256) unsafeAtomicAdd(dw + i, sh[i]);
+  for (int i = tid; i < OC; i += 256) unsafeAtomicAdd(db + i, sh[OC * C + i]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int cm_head_fwd(const float* x, long long sx, const float* w, const float* b, float* pred, int n, int c, int oc,
+                int hw, cm_stream stream) {
+  if (n <= 0 || c <= 0 || oc <= 0 || oc > MAXOC || hw <= 0) return -22;
+  head_fwd_kernel<<<dim3(cdiv(hw, 256), n), 256, 0, (hipStream_t)stream>>>(x, sx, w, b, pred, c, oc, hw);
+  CM_CHECK_LAUNCH();
+  return 0;
+}
+
+int cm_mse_loss(const float* pred, const float* y, float* loss, float* dpred, long long total, cm_stream stream) {
+  if (total <= 0) return -22;
+  hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  mse_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(pred, y, loss, dpred, total);
+  CM_CHECK_LAUNCH();
+  return 0;
+}
+
+int cm_head_bwd(const float* dpred, const float* x, long long sx, const float* w, float* dx, long long sdx, float* dw,
+                float* db, int n, int c, int oc, int hw, cm_stream stream) {
+  if (n <= 0 || c <= 0 || oc <= 0 || oc > MAXOC || hw <= 0) return -22;
+  const int tiles = cdiv(hw, 256);
+  const int tpb = tiles >= 8 ? 4 : 1;
+  head_bwd_kernel<<<dim3(cdiv(tiles, tpb), n), 256, (oc * c + oc) * sizeof(float), (hipStream_t)stream>>>(
+      dpred, x, sx, w, dx, sdx, dw, db, c, oc, hw, tpb);
+  CM_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,210 @@
+"""Hot-path engine: forward and backward of the unet_convlstm_attention model as a sequence of HIP launches.
+
+This is the host-side schedule that replaces ``AttUNetConvLSTM.forward`` (reference src/unet_convlstm_attention.py:60-104)
+and the autograd graph behind ``loss.backward()`` (main_final.py:556-561).  It only orders ``cm_*`` launches on the
+current HIP stream and keeps the tensors the backward needs; there is no math in Python and no CPU fallback.  Because
+every launch is capture-safe, a whole training step can be recorded into one hipGraph (see ``trainer.GraphedStep``).
+
+Layout decisions:
+  * the frame loop of the encoder is folded into the batch: encoder tensors are [B*T, C, H, W], sample n = b*T + t
+    (x_seq [B,T,C,H,W] is viewed, not copied; GroupNorm / SE / spatial gate are per-sample so results are unchanged);
+  * the ConvLSTM input projection W_x * s4_t has no recurrence and runs once for all T; only W_h * h_{t-1} is
+    sequential.  Gate buffers are [B,T,4*Ch,h,w]; step t works on the strided slice [:, t] in place;
+  * torch.cat([up, skip]) is never materialised: the conv kernels take two input pointers.
+"""
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+
+Tensor = torch.Tensor
+Params = Dict[str, Tensor]
+
+
+class _BlockCtx:
+    """Tensors one ConvBlock keeps for its backward."""
+    __slots__ = ("x0", "x1", "y1", "a1", "st1", "y2", "a2", "st2", "pooled", "z", "s", "fmap", "gate", "out")
+
+
+def pack_weights(p: Params, need_input_grad: bool = False) -> Dict[str, Tensor]:
+    """MFMA operand layouts of every 3x3 weight: forward and data-gradient forms (re-run whenever params change)."""
+    pk: Dict[str, Tensor] = {}
+    for name, w in p.items():
+        if not (name.endswith("body.0.weight") or name.endswith("body.3.weight")):
+            continue
+        pk[name + "/f"] = ops.pack_conv3x3(w)
+        if name != "enc1.body.0.weight" or need_input_grad:
+            pk[name + "/d"] = ops.pack_conv3x3(w, dgrad=True)
+    wl = p["convlstm.cell.conv.weight"]
+    ch = wl.shape[0] // 4
+    cx = wl.shape[1] - ch
+    pk["lstm.x/f"] = ops.pack_conv3x3(wl, c_off=0, cin=cx)
+    pk["lstm.h/f"] = ops.pack_conv3x3(wl, c_off=cx, cin=ch)
+    pk["lstm.x/d"] = ops.pack_conv3x3(wl, c_off=0, cin=cx, dgrad=True)
+    pk["lstm.h/d"] = ops.pack_conv3x3(wl, c_off=cx, cin=ch, dgrad=True)
+    return pk
+
+
+# ------------------------------------------------------------------------------------------------- ConvBlock
+def _block_fwd(p: Params, pk, prefix: str, x0: Tensor, x1: Optional[Tensor], save: bool):
+    co = p[prefix + "body.0.weight"].shape[0]
+    y1 = ops.conv3x3(x0, pk[prefix + "body.0.weight/f"], co, x1=x1)
+    a1, st1, _ = ops.gn_silu_fwd(y1, p[prefix + "body.1.weight"], p[prefix + "body.1.bias"])
+    y2 = ops.conv3x3(a1, pk[prefix + "body.3.weight/f"], co)
+    a2, st2, pooled = ops.gn_silu_fwd(y2, p[prefix + "body.4.weight"], p[prefix + "body.4.bias"], want_pooled=True)
+    z, s = ops.se_excite_fwd(pooled, p[prefix + "se.fc.0.weight"], p[prefix + "se.fc.2.weight"])
+    out, fmap, gate = ops.spatial_gate_fwd(a2, s, p[prefix + "spat.conv.weight"])
+    ctx = None
+    if save:
+        ctx = _BlockCtx()
+        ctx.x0, ctx.x1, ctx.y1, ctx.a1, ctx.st1, ctx.y2, ctx.a2, ctx.st2 = x0, x1, y1, a1, st1, y2, a2, st2
+        ctx.pooled, ctx.z, ctx.s, ctx.fmap, ctx.gate, ctx.out = pooled, z, s, fmap, gate, out
+    return out, ctx
+
+
+def _block_bwd(p: Params, pk, g: Params, prefix: str, ctx: _BlockCtx, dout: Tensor, need_dx: bool = True):
+    """Returns d(input) as one tensor [N, C0+C1, H, W] (or None); parameter gradients are accumulated into ``g``."""
+    co = ctx.y1.shape[1]
+    w1, w2, w7 = p[prefix + "se.fc.0.weight"], p[prefix + "se.fc.2.weight"], p[prefix + "spat.conv.weight"]
+    dmap, cnt, dpool = ops.gates_bwd(dout, ctx.a2, ctx.s, ctx.z, ctx.pooled, ctx.gate, ctx.fmap, w1, w2, w7,
+                                     g[prefix + "se.fc.0.weight"], g[prefix + "se.fc.2.weight"],
+                                     g[prefix + "spat.conv.weight"])
+    dy2 = ops.gn_silu_bwd_gated(ctx.y2, p[prefix + "body.4.weight"], p[prefix + "body.4.bias"], ctx.st2, ctx.a2, dout,
+                                ctx.gate, dmap, ctx.fmap, cnt, ctx.s, dpool, g[prefix + "body.4.weight"],
+                                g[prefix + "body.4.bias"])
+    gw = torch.zeros(co, 9, co, device=dout.device, dtype=torch.float32)
+    ops.wgrad3x3(ctx.a1, dy2, gw)
+    _unpack_into(gw, g[prefix + "body.3.weight"])
+    da1 = ops.conv3x3(dy2, pk[prefix + "body.3.weight/d"], co)
+    dy1 = ops.gn_silu_bwd(ctx.y1, p[prefix + "body.1.weight"], p[prefix + "body.1.bias"], ctx.st1, da1,
+                          g[prefix + "body.1.weight"], g[prefix + "body.1.bias"])
+    ci = ctx.x0.shape[1] + (0 if ctx.x1 is None else ctx.x1.shape[1])
+    gw = torch.zeros(co, 9, ci, device=dout.device, dtype=torch.float32)
+    ops.wgrad3x3(ctx.x0, dy1, gw, x1=ctx.x1)
+    _unpack_into(gw, g[prefix + "body.0.weight"])
+    if not need_dx:
+        return None
+    return ops.conv3x3(dy1, pk[prefix + "body.0.weight/d"], ci)
+
+
+def _unpack_into(gw: Tensor, dst: Tensor) -> None:
+    from ._lib import check, lib
+    cout, _, ctot = gw.shape
+    check(lib.cm_wgrad3x3_unpack(gw.data_ptr(), dst.data_ptr(), cout, ctot, 1.0,
+                                 torch.cuda.current_stream().cuda_stream), "unpack")
+
+
+# ------------------------------------------------------------------------------------------------- whole model
+class Saved:
+    """Everything the backward needs from one forward."""
+    __slots__ = ("B", "T", "enc", "pools_in", "s4", "gx", "hprev", "call", "bott", "ups", "up_in", "d1", "x_shape")
+
+
+def forward(p: Params, pk, x_seq: Tensor, save: bool = True):
+    """x_seq [B,T,C,H,W] (contiguous, fp32, GPU) -> pred [B,out_ch,H,W], Saved."""
+    if x_seq.dim() != 5:
+        raise RuntimeError("expected x_seq of shape [B, T, C, H, W]")
+    B, T, C, H, W = x_seq.shape
+    if C != p["enc1.body.0.weight"].shape[1]:
+        raise RuntimeError(f"channel mismatch: input has {C} channels, enc1 expects "
+                           f"{p['enc1.body.0.weight'].shape[1]}")
+    if H % 8 or W % 8:
+        raise RuntimeError("H and W must be divisible by 8 (three 2x2 poolings)")
+    x = x_seq.contiguous().view(B * T, C, H, W)
+    sv = Saved() if save else None
+
+    # ---- encoder, all frames at once -------------------------------------------------------------------
+    s1, c1 = _block_fwd(p, pk, "enc1.", x, None, save)
+    p1 = ops.maxpool2_fwd(s1)
+    s2, c2 = _block_fwd(p, pk, "enc2.conv.", p1, None, save)
+    p2 = ops.maxpool2_fwd(s2)
+    s3, c3 = _block_fwd(p, pk, "enc3.conv.", p2, None, save)
+    p3 = ops.maxpool2_fwd(s3)
+    s4, c4 = _block_fwd(p, pk, "enc4.conv.", p3, None, save)
+
+    # ---- ConvLSTM bottleneck ---------------------------------------------------------------------------
+    wl, bl = p["convlstm.cell.conv.weight"], p["convlstm.cell.conv.bias"]
+    ch = wl.shape[0] // 4
+    h8, w8 = H // 8, W // 8
+    gx = ops.conv3x3(s4, pk["lstm.x/f"], 4 * ch, bias=bl).view(B, T, 4 * ch, h8, w8)
+    hprev = torch.empty(B, T, ch, h8, w8, device=x.device, dtype=torch.float32)
+    hprev[:, 0].zero_()
+    call = torch.empty(B, T, ch, h8, w8, device=x.device, dtype=torch.float32)
+    bott = torch.empty(B, ch, h8, w8, device=x.device, dtype=torch.float32)
+    for t in range(T):
+        if t > 0:
+            ops.conv3x3(hprev[:, t], pk["lstm.h/f"], 4 * ch, resid=gx[:, t], out=gx[:, t])
+        ops.lstm_gates_fwd(gx[:, t], call[:, t - 1] if t > 0 else None, call[:, t],
+                           hprev[:, t + 1] if t + 1 < T else bott)
+
+    # ---- time-mean skips + decoder ---------------------------------------------------------------------
+    k1, k2, k3 = ops.time_mean(s1, B, T), ops.time_mean(s2, B, T), ops.time_mean(s3, B, T)
+    u3 = ops.convT2x2_fwd(bott, p["up3.up.weight"], p["up3.up.bias"])
+    d3, cu3 = _block_fwd(p, pk, "up3.conv.", u3, k3, save)
+    u2 = ops.convT2x2_fwd(d3, p["up2.up.weight"], p["up2.up.bias"])
+    d2, cu2 = _block_fwd(p, pk, "up2.conv.", u2, k2, save)
+    u1 = ops.convT2x2_fwd(d2, p["up1.up.weight"], p["up1.up.bias"])
+    d1, cu1 = _block_fwd(p, pk, "up1.conv.", u1, k1, save)
+    pred = ops.head_fwd(d1, p["head.weight"], p["head.bias"])
+
+    if save:
+        sv.B, sv.T, sv.x_shape = B, T, tuple(x_seq.shape)
+        sv.enc = (c1, c2, c3, c4)
+        sv.s4, sv.gx, sv.hprev, sv.call, sv.bott = s4, gx, hprev, call, bott
+        sv.ups = (cu3, cu2, cu1)
+        sv.up_in = (bott, d3, d2)
+        sv.d1 = d1
+    return pred, sv
+
+
+def backward(p: Params, pk, g: Params, sv: Saved, dpred: Tensor, need_dx: bool = False):
+    """Accumulates every parameter gradient into ``g`` (same keys as ``p``; the caller zeroes them) and returns
+    d(x_seq) when ``need_dx``.  ``post_conv.*`` is untouched (never used by the forward, as in the reference)."""
+    B, T = sv.B, sv.T
+    c1, c2, c3, c4 = sv.enc
+    cu3, cu2, cu1 = sv.ups
+    bott, d3, d2 = sv.up_in
+
+    # ---- head + decoder --------------------------------------------------------------------------------
+    dd1 = ops.head_bwd(dpred, sv.d1, p["head.weight"], g["head.weight"], g["head.bias"])
+    dcat1 = _block_bwd(p, pk, g, "up1.conv.", cu1, dd1)
+    b1 = cu1.x0.shape[1]
+    dd2 = ops.convT2x2_bwd(d2, p["up1.up.weight"], dcat1[:, :b1], g["up1.up.weight"], g["up1.up.bias"])
+    dcat2 = _block_bwd(p, pk, g, "up2.conv.", cu2, dd2)
+    b2 = cu2.x0.shape[1]
+    dd3 = ops.convT2x2_bwd(d3, p["up2.up.weight"], dcat2[:, :b2], g["up2.up.weight"], g["up2.up.bias"])
+    dcat3 = _block_bwd(p, pk, g, "up3.conv.", cu3, dd3)
+    b3 = cu3.x0.shape[1]
+    dbott = ops.convT2x2_bwd(bott, p["up3.up.weight"], dcat3[:, :b3], g["up3.up.weight"], g["up3.up.bias"])
+
+    # ---- ConvLSTM, back through time -------------------------------------------------------------------
+    gx, hprev, call = sv.gx, sv.hprev, sv.call
+    ch = hprev.shape[2]
+    cx = sv.s4.shape[1]
+    h8, w8 = hprev.shape[3], hprev.shape[4]
+    dc = torch.empty(B, ch, h8, w8, device=dpred.device, dtype=torch.float32)
+    dhrec = None
+    for t in range(T - 1, -1, -1):
+        ops.lstm_gates_bwd(gx[:, t], call[:, t - 1] if t > 0 else None, call[:, t], dbott if t == T - 1 else None,
+                           dhrec, dc, first=(t == T - 1))
+        if t > 0:
+            dhrec = ops.conv3x3(gx[:, t], pk["lstm.h/d"], ch)
+    dA = gx.view(B * T, 4 * ch, h8, w8)            # now holds d(pre-activations) for every (b, t)
+    gw = torch.zeros(4 * ch, 9, cx + ch, device=dpred.device, dtype=torch.float32)
+    ops.wgrad3x3(sv.s4, dA, gw, c_off=0)
+    if T > 1:
+        ops.wgrad3x3(hprev.view(B * T, ch, h8, w8), dA, gw, c_off=cx)   # hprev[:, 0] == 0 contributes nothing
+    _unpack_into(gw, g["convlstm.cell.conv.weight"])
+    ops.channel_sum(dA, g["convlstm.cell.conv.bias"])
+    ds4 = ops.conv3x3(dA, pk["lstm.x/d"], cx)
+
+    # ---- encoder ---------------------------------------------------------------------------------------
+    dp3 = _block_bwd(p, pk, g, "enc4.conv.", c4, ds4)
+    ds3 = ops.maxpool2_bwd(c3.out, dp3, dcat3[:, b3:], t=T)
+    dp2 = _block_bwd(p, pk, g, "enc3.conv.", c3, ds3)
+    ds2 = ops.maxpool2_bwd(c2.out, dp2, dcat2[:, b2:], t=T)
+    dp1 = _block_bwd(p, pk, g, "enc2.conv.", c2, ds2)
+    ds1 = ops.maxpool2_bwd(c1.out, dp1, dcat1[:, b1:], t=T)
+    dx = _block_bwd(p, pk, g, "enc1.", c1, ds1, need_dx=need_dx)
+    return dx.view(sv.x_shape) if dx is not None else None

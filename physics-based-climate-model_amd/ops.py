@@ -1,0 +1,242 @@
+"""Tensor-level wrappers over the C ABI (one Python function per ``cm_*`` launcher).
+
+torch supplies device memory and the current HIP stream only; every function enqueues hand-written HIP kernels from
+libclimate_hip.so.  There is deliberately no CPU implementation here: calling these with CPU tensors raises.
+"""
+import torch
+
+from ._lib import check, lib
+
+GN_GROUPS = 8
+GN_EPS = 1e-5
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise RuntimeError("climate_hip ops need float32 tensors on the GPU (no CPU fallback)")
+    return t.data_ptr()
+
+
+def _contig(t):
+    if not t.is_contiguous():
+        raise RuntimeError("climate_hip ops need contiguous tensors")
+    return t
+
+
+# ----------------------------------------------------------------------------------------------------- conv3x3
+def pack_conv3x3(w, c_off=0, cin=None, dgrad=False):
+    cout, cin_total = w.shape[0], w.shape[1]
+    cin = cin_total - c_off if cin is None else cin
+    n = lib.cm_conv3x3_packed_elems(cout if dgrad else cin, cin if dgrad else cout)
+    wp = torch.empty(n, device=w.device, dtype=torch.float32)
+    check(lib.cm_pack_conv3x3(_p(_contig(w)), cout, cin_total, c_off, cin, int(dgrad), _p(wp), _stream()), "pack")
+    return wp
+
+
+def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1):
+    """out = conv3x3(cat(x0, x1), wp) + bias + resid.  x0/x1: [N,C,H,W] (sample stride may exceed C*H*W)."""
+    n, c0, h, w = x0.shape
+    c1 = 0 if x1 is None else x1.shape[1]
+    if out is None:
+        out = torch.empty(n, cout, h, w, device=x0.device, dtype=torch.float32)
+    for t in (x0, x1, out, resid):
+        if t is not None and (t.stride(3) != 1 or t.stride(2) != w or t.stride(1) != h * w):
+            raise RuntimeError("conv3x3 needs dense HxW planes with channel stride H*W")
+    check(lib.cm_conv3x3(_p(x0), x0.stride(0), c0, _p(x1), 0 if x1 is None else x1.stride(0), c1, _p(wp), _p(bias),
+                         _p(resid), 0 if resid is None else resid.stride(0), _p(out), out.stride(0), n, h, w, cout,
+                         config, _stream()), "conv3x3")
+    return out
+
+
+def wgrad3x3(x0, dy, g, c_off=0, x1=None, config=-1):
+    """g[cout][9][ctot] += wgrad(cat(x0, x1), dy) for input-channel range [c_off, ...)."""
+    n, c0, h, w = x0.shape
+    c1 = 0 if x1 is None else x1.shape[1]
+    cout, ctot = g.shape[0], g.shape[2]
+    check(lib.cm_wgrad3x3(_p(x0), x0.stride(0), c0, _p(x1), 0 if x1 is None else x1.stride(0), c1, _p(dy),
+                          dy.stride(0), _p(g), ctot, c_off, n, h, w, cout, config, _stream()), "wgrad3x3")
+    return g
+
+
+def wgrad3x3_unpack(g, scale=1.0):
+    cout, _, ctot = g.shape
+    dw = torch.empty(cout, ctot, 3, 3, device=g.device, dtype=torch.float32)
+    check(lib.cm_wgrad3x3_unpack(_p(g), _p(dw), cout, ctot, scale, _stream()), "unpack")
+    return dw
+
+
+# ----------------------------------------------------------------------------------------------------- GN + SiLU
+def gn_silu_fwd(x, gamma, beta, want_pooled=False):
+    n, c, h, w = x.shape
+    y = torch.empty_like(_contig(x))
+    stats = torch.empty(n * GN_GROUPS * 2, device=x.device, dtype=torch.float32)
+    pooled = torch.empty(n, c, device=x.device, dtype=torch.float32) if want_pooled else None
+    check(lib.cm_gn_silu_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), _p(pooled), n, c, h * w, GN_GROUPS, GN_EPS,
+                             _stream()), "gn_silu_fwd")
+    return y, stats, pooled
+
+
+def gn_silu_bwd(x, gamma, beta, stats, dA, dgamma, dbeta):
+    n, c, h, w = x.shape
+    dx = torch.empty_like(_contig(x))
+    check(lib.cm_gn_silu_bwd(_p(x), _p(gamma), _p(beta), _p(stats), _p(dA), dA.stride(0), _p(dx), _p(dgamma),
+                             _p(dbeta), n, c, h * w, GN_GROUPS, _stream()), "gn_silu_bwd")
+    return dx
+
+
+def gn_silu_bwd_gated(x, gamma, beta, stats, a2, dout, gate, dmap, fmap, cnt, s, dpool, dgamma, dbeta):
+    n, c, h, w = x.shape
+    dx = torch.empty_like(_contig(x))
+    check(lib.cm_gn_silu_bwd_gated(_p(x), _p(gamma), _p(beta), _p(stats), _p(a2), _p(_contig(dout)), _p(gate),
+                                   _p(dmap), _p(fmap), _p(cnt), _p(s), _p(dpool), _p(dx), _p(dgamma), _p(dbeta), n, c,
+                                   h * w, GN_GROUPS, _stream()), "gn_silu_bwd_gated")
+    return dx
+
+
+# ----------------------------------------------------------------------------------------------------- gates
+def se_excite_fwd(pooled, w1, w2):
+    n, c = pooled.shape
+    cr = w1.shape[0]
+    z = torch.empty(n, cr, device=pooled.device, dtype=torch.float32)
+    s = torch.empty(n, c, device=pooled.device, dtype=torch.float32)
+    check(lib.cm_se_excite_fwd(_p(pooled), _p(_contig(w1)), _p(_contig(w2)), _p(z), _p(s), n, c, cr, _stream()), "se")
+    return z, s
+
+
+def spatial_gate_fwd(a2, s, w7):
+    n, c, h, w = a2.shape
+    fmap = torch.empty(n, 2, h, w, device=a2.device, dtype=torch.float32)
+    gate = torch.empty(n, h, w, device=a2.device, dtype=torch.float32)
+    out = torch.empty_like(_contig(a2))
+    check(lib.cm_spatial_stats(_p(a2), _p(s), _p(fmap), n, c, h * w, _stream()), "spatial_stats")
+    check(lib.cm_spatial_apply(_p(a2), _p(s), _p(fmap), _p(_contig(w7)), _p(gate), _p(out), n, c, h, w, _stream()),
+          "spatial_apply")
+    return out, fmap, gate
+
+
+def gates_bwd(dout, a2, s, z, pooled, gate, fmap, w1, w2, w7, dw1, dw2, dw7):
+    """Backward of SE + spatial gate up to (but excluding) the GroupNorm; returns the maps cm_gn_silu_bwd_gated needs."""
+    n, c, h, w = a2.shape
+    cr = w1.shape[0]
+    dev = a2.device
+    dgpre = torch.empty(n, h, w, device=dev, dtype=torch.float32)
+    cnt = torch.empty(n, h, w, device=dev, dtype=torch.float32)
+    dmap = torch.empty(n, 2, h, w, device=dev, dtype=torch.float32)
+    ds = torch.empty(n, c, device=dev, dtype=torch.float32)
+    dsig = torch.empty(n, c, device=dev, dtype=torch.float32)
+    dz = torch.empty(n, cr, device=dev, dtype=torch.float32)
+    dpool = torch.empty(n, c, device=dev, dtype=torch.float32)
+    st = _stream()
+    check(lib.cm_gate_bwd_reduce(_p(_contig(dout)), _p(a2), _p(s), _p(gate), _p(fmap), _p(dgpre), _p(cnt), n, c, h * w,
+                                 st), "gate_bwd_reduce")
+    check(lib.cm_conv7_bwd(_p(dgpre), _p(fmap), _p(_contig(w7)), _p(dmap), _p(dw7), n, h, w, st), "conv7_bwd")
+    check(lib.cm_se_bwd_reduce(_p(dout), _p(a2), _p(s), _p(gate), _p(dmap), _p(fmap), _p(cnt), _p(ds), n, c, h * w, st),
+          "se_bwd_reduce")
+    check(lib.cm_se_excite_bwd(_p(ds), _p(s), _p(z), _p(pooled), _p(_contig(w1)), _p(_contig(w2)), _p(dsig), _p(dz),
+                               _p(dpool), _p(dw1), _p(dw2), n, c, cr, st), "se_excite_bwd")
+    return dmap, cnt, dpool
+
+
+# ----------------------------------------------------------------------------------------------------- pool / skip
+def maxpool2_fwd(x):
+    n, c, h, w = x.shape
+    y = torch.empty(n, c, h // 2, w // 2, device=x.device, dtype=torch.float32)
+    check(lib.cm_maxpool2_fwd(_p(_contig(x)), _p(y), n * c, h, w, _stream()), "maxpool")
+    return y
+
+
+def maxpool2_bwd(x, dy, dskip=None, t=1):
+    n, c, h, w = x.shape
+    dx = torch.empty_like(_contig(x))
+    check(lib.cm_maxpool2_bwd(_p(x), _p(_contig(dy)), _p(dskip), 0 if dskip is None else dskip.stride(0), _p(dx), n, c,
+                              h, w, t, 1.0 / t, _stream()), "maxpool_bwd")
+    return dx
+
+
+def time_mean(x, b, t):
+    chw = x[0].numel()
+    y = torch.empty((b,) + tuple(x.shape[1:]), device=x.device, dtype=torch.float32)
+    check(lib.cm_time_mean(_p(_contig(x)), _p(y), b, t, chw, _stream()), "time_mean")
+    return y
+
+
+def channel_sum(x, out):
+    n, c, h, w = x.shape
+    check(lib.cm_channel_sum(_p(x), x.stride(0), _p(out), n, c, h * w, _stream()), "channel_sum")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------- convT
+def convT2x2_fwd(x, w, b):
+    n, ci, h, wd = x.shape
+    co = w.shape[1]
+    y = torch.empty(n, co, 2 * h, 2 * wd, device=x.device, dtype=torch.float32)
+    check(lib.cm_convT2x2_fwd(_p(x), x.stride(0), _p(_contig(w)), _p(b), _p(y), y.stride(0), n, ci, co, h, wd,
+                              _stream()), "convT_fwd")
+    return y
+
+
+def convT2x2_bwd(x, w, dy, dw, db):
+    n, ci, h, wd = x.shape
+    co = w.shape[1]
+    dx = torch.empty(n, ci, h, wd, device=x.device, dtype=torch.float32)
+    st = _stream()
+    check(lib.cm_convT2x2_bwd_data(_p(dy), dy.stride(0), _p(_contig(w)), _p(dx), dx.stride(0), n, ci, co, h, wd, st),
+          "convT_bwd_data")
+    check(lib.cm_convT2x2_bwd_weight(_p(x), x.stride(0), _p(dy), dy.stride(0), _p(dw), n, ci, co, h, wd, st),
+          "convT_bwd_weight")
+    check(lib.cm_channel_sum(_p(dy), dy.stride(0), _p(db), n, co, 4 * h * wd, st), "convT_bias")
+    return dx
+
+
+# ----------------------------------------------------------------------------------------------------- lstm / head
+def lstm_gates_fwd(gates, c_prev, c_out, h_out):
+    b, ch4, h, w = gates.shape
+    ch = ch4 // 4
+    check(lib.cm_lstm_gates_fwd(_p(gates), gates.stride(0), _p(c_prev), 0 if c_prev is None else c_prev.stride(0),
+                                _p(c_out), c_out.stride(0), _p(h_out), h_out.stride(0), b, ch, h * w, _stream()),
+          "lstm_fwd")
+
+
+def lstm_gates_bwd(gates, c_prev, c_cur, dh_a, dh_b, dc, first):
+    b, ch4, h, w = gates.shape
+    ch = ch4 // 4
+    check(lib.cm_lstm_gates_bwd(_p(gates), gates.stride(0), _p(c_prev), 0 if c_prev is None else c_prev.stride(0),
+                                _p(c_cur), c_cur.stride(0), _p(dh_a), 0 if dh_a is None else dh_a.stride(0), _p(dh_b),
+                                0 if dh_b is None else dh_b.stride(0), _p(_contig(dc)), int(first), b, ch, h * w,
+                                _stream()), "lstm_bwd")
+
+
+def head_fwd(x, w, b):
+    n, c, h, wd = x.shape
+    oc = w.shape[0]
+    pred = torch.empty(n, oc, h, wd, device=x.device, dtype=torch.float32)
+    check(lib.cm_head_fwd(_p(x), x.stride(0), _p(_contig(w)), _p(b), _p(pred), n, c, oc, h * wd, _stream()), "head_fwd")
+    return pred
+
+
+def mse_loss(pred, y, want_grad=True):
+    loss = torch.empty(1, device=pred.device, dtype=torch.float32)
+    dpred = torch.empty_like(pred) if want_grad else None
+    check(lib.cm_mse_loss(_p(_contig(pred)), _p(_contig(y)), _p(loss), _p(dpred), pred.numel(), _stream()), "mse")
+    return loss, dpred
+
+
+def head_bwd(dpred, x, w, dw, db):
+    n, c, h, wd = x.shape
+    oc = w.shape[0]
+    dx = torch.empty(n, c, h, wd, device=x.device, dtype=torch.float32)
+    check(lib.cm_head_bwd(_p(_contig(dpred)), _p(x), x.stride(0), _p(_contig(w)), _p(dx), dx.stride(0), _p(dw), _p(db),
+                          n, c, oc, h * wd, _stream()), "head_bwd")
+    return dx
+
+
+def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    check(lib.cm_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
+                           grad_scale, _stream()), "adam")

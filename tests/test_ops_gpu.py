@@ -1,0 +1,323 @@
+"""Parity of every HIP launcher (through the C ABI) against the CPU oracle / torch-CPU fp64 on seeded inputs.
+
+Tolerance: relative L2 <= 1e-4 (north_star's fp32 bound); observed values are ~1e-6.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+from conftest import load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from climate_amd import ops as o
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator("cpu").manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+# --------------------------------------------------------------------------------------------- MFMA layout probe
+def test_conv_identity_asymmetric(ops):
+    """A = I style probe: a centre-tap identity kernel with an asymmetric input must reproduce the input exactly;
+    catches row/col swaps in the MFMA operand/accumulator maps."""
+    n, c, h, w = 2, 32, 8, 24
+    x = torch.arange(n * c * h * w, dtype=torch.float32).reshape(n, c, h, w) * 1e-3
+    wt = torch.zeros(c, c, 3, 3)
+    for i in range(c):
+        wt[i, i, 1, 1] = 1.0
+    wp = ops.pack_conv3x3(dev(wt))
+    for cfg in range(13):
+        y = ops.conv3x3(dev(x), wp, c, config=cfg)
+        assert torch.equal(y.cpu(), x), f"config {cfg}"
+    # permutation of channels + a shifted tap
+    wt = torch.zeros(c, c, 3, 3)
+    for i in range(c):
+        wt[i, (i * 7 + 3) % c, 0, 2] = 1.0
+    wp = ops.pack_conv3x3(dev(wt))
+    ref = F.conv2d(x, wt, padding=1)
+    y = ops.conv3x3(dev(x), wp, c, config=0)
+    assert torch.equal(y.cpu(), ref)
+
+
+CONV_CASES = [
+    # n, c0, c1, cout, h, w
+    (3, 5, 0, 16, 16, 24),
+    (2, 8, 16, 32, 12, 18),
+    (5, 40, 0, 70, 10, 14),
+    (7, 16, 0, 64, 6, 9),
+    (2, 32, 0, 8, 48, 72),
+    (1, 24, 8, 96, 24, 36),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3x3_all_configs(ops, case):
+    n, c0, c1, cout, h, w = case
+    x0 = rnd(n, c0, h, w, seed=1)
+    x1 = rnd(n, c1, h, w, seed=2) if c1 else None
+    wt = rnd(cout, c0 + c1, 3, 3, seed=3, scale=(9 * (c0 + c1)) ** -0.5)
+    b = rnd(cout, seed=4)
+    r = rnd(n, cout, h, w, seed=5)
+    xin = x0 if x1 is None else torch.cat([x0, x1], 1)
+    ref = F.conv2d(xin.double(), wt.double(), b.double(), padding=1) + r.double()
+    wp = ops.pack_conv3x3(dev(wt))
+    for cfg in list(range(13)) + [-1]:
+        y = ops.conv3x3(dev(x0), wp, cout, x1=None if x1 is None else dev(x1), bias=dev(b), resid=dev(r), config=cfg)
+        assert rel_l2(y, ref) < TOL, f"config {cfg}: {rel_l2(y, ref)}"
+
+
+@pytest.mark.parametrize("case", CONV_CASES[:4])
+def test_conv3x3_dgrad(ops, case):
+    n, c0, c1, cout, h, w = case
+    cin = c0 + c1
+    wt = rnd(cout, cin + 3, 3, 3, seed=6, scale=(9 * cin) ** -0.5)   # weight has 3 extra leading channels
+    dy = rnd(n, cout, h, w, seed=7)
+    x = torch.zeros(n, cin, h, w, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x, wt[:, 3:].double(), padding=1)
+    y.backward(dy.double())
+    wp = ops.pack_conv3x3(dev(wt), c_off=3, cin=cin, dgrad=True)
+    dx = ops.conv3x3(dev(dy), wp, cin)
+    assert rel_l2(dx, x.grad) < TOL
+
+
+def test_conv3x3_strided_views(ops):
+    """time slices of a [B,T,C,H,W] buffer: pointer offset + sample stride T*C*H*W, in-place residual."""
+    b, t, c, cout, h, w = 4, 3, 16, 32, 6, 9
+    hseq = rnd(b, t, c, h, w, seed=8)
+    gx = rnd(b, t, cout, h, w, seed=9)
+    wt = rnd(cout, c, 3, 3, seed=10, scale=0.1)
+    hd, gd = dev(hseq), dev(gx)
+    wp = ops.pack_conv3x3(dev(wt))
+    ops.conv3x3(hd[:, 1], wp, cout, resid=gd[:, 2], out=gd[:, 2])
+    ref = gx.clone().double()
+    ref[:, 2] += F.conv2d(hseq[:, 1].double(), wt.double(), padding=1)
+    assert rel_l2(gd, ref) < TOL
+
+
+WG_CASES = [
+    (3, 5, 0, 16, 16, 24),
+    (2, 8, 16, 32, 12, 18),
+    (5, 40, 0, 70, 10, 14),
+    (6, 32, 0, 64, 6, 9),
+    (2, 16, 0, 32, 48, 72),
+]
+
+
+@pytest.mark.parametrize("case", WG_CASES)
+def test_wgrad3x3_all_configs(ops, case):
+    n, c0, c1, cout, h, w = case
+    x0 = rnd(n, c0, h, w, seed=11)
+    x1 = rnd(n, c1, h, w, seed=12) if c1 else None
+    dy = rnd(n, cout, h, w, seed=13)
+    xin = x0 if x1 is None else torch.cat([x0, x1], 1)
+    wt = torch.zeros(cout, c0 + c1, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xin.double(), wt, padding=1).backward(dy.double())
+    ctot = c0 + c1 + 4
+    for cfg in list(range(7)) + [-1]:
+        g = torch.zeros(cout, 9, ctot, device="cuda")
+        ops.wgrad3x3(dev(x0), dev(dy), g, c_off=4, x1=None if x1 is None else dev(x1), config=cfg)
+        dw = ops.wgrad3x3_unpack(g)
+        assert rel_l2(dw[:, 4:], wt.grad) < TOL, f"config {cfg}: {rel_l2(dw[:, 4:], wt.grad)}"
+        assert dw[:, :4].abs().max().item() == 0.0
+
+
+# --------------------------------------------------------------------------------------------- GN + SiLU
+@pytest.mark.parametrize("shape", [(3, 16, 6, 9), (2, 32, 16, 24), (2, 8, 12, 18), (1, 64, 48, 72)])
+def test_gn_silu(ops, shape):
+    n, c, h, w = shape
+    x = rnd(*shape, seed=20) * 2 + 0.7
+    gamma = 1 + 0.2 * rnd(c, seed=21)
+    beta = 0.1 * rnd(c, seed=22)
+    dA = rnd(*shape, seed=23)
+    xd = x.double().requires_grad_(); gd = gamma.double().requires_grad_(); bd = beta.double().requires_grad_()
+    ref = F.silu(F.group_norm(xd, 8, gd, bd, 1e-5))
+    ref.backward(dA.double())
+    y, stats, pooled = ops.gn_silu_fwd(dev(x), dev(gamma), dev(beta), want_pooled=True)
+    assert rel_l2(y, ref) < TOL
+    assert rel_l2(pooled, ref.mean((2, 3))) < TOL
+    dg = torch.zeros(c, device="cuda"); db = torch.zeros(c, device="cuda")
+    dx = ops.gn_silu_bwd(dev(x), dev(gamma), dev(beta), stats, dev(dA), dg, db)
+    assert rel_l2(dx, xd.grad) < TOL and rel_l2(dg, gd.grad) < TOL and rel_l2(db, bd.grad) < TOL
+
+
+# --------------------------------------------------------------------------------------------- SE + spatial gate
+def _gates_roundtrip(ops, a2, w1, w2, w7, dout, gamma=None, beta=None, y2=None):
+    """Runs SE + spatial gate forward and the full backward chain; returns (out, d_a2 or d_y2, dw1, dw2, dw7)."""
+    n, c, h, w = a2.shape
+    pooled = a2.mean((2, 3))
+    z, s = ops.se_excite_fwd(dev(pooled), dev(w1), dev(w2))
+    out, fmap, gate = ops.spatial_gate_fwd(dev(a2), s, dev(w7))
+    dw1 = torch.zeros_like(dev(w1)); dw2 = torch.zeros_like(dev(w2)); dw7 = torch.zeros_like(dev(w7))
+    dmap, cnt, dpool = ops.gates_bwd(dev(dout), dev(a2), s, z, dev(pooled), gate, fmap, dev(w1), dev(w2), dev(w7), dw1,
+                                     dw2, dw7)
+    return out, (s, fmap, gate, dmap, cnt, dpool), dw1, dw2, dw7
+
+
+def test_se_and_spatial_gate_golden(ops):
+    """SE and SpatialGate fixtures from the reference (incl. amax ties): forward through the HIP kernels."""
+    g = load_golden("se_block.npz")
+    x = g["x"]
+    z, s = ops.se_excite_fwd(dev(x.mean((2, 3))), dev(g["w1"]), dev(g["w2"]))
+    assert rel_l2(dev(x) * s[:, :, None, None], g["y"]) < TOL
+    g = load_golden("spatial_gate.npz")
+    x = g["x"]
+    ones = torch.ones(x.shape[0], x.shape[1], device="cuda")
+    out, fmap, gate = ops.spatial_gate_fwd(dev(x), ones, dev(g["w7"]))
+    assert rel_l2(out, g["y"]) < TOL
+
+
+def test_conv_block_chain_golden(ops):
+    """ConvBlock forward + backward composed from the launchers vs the reference fixture (conv_block.npz)."""
+    g = load_golden("conv_block.npz")
+    P = {k[2:]: dev(v) for k, v in g.items() if k.startswith("p.")}
+    x, dy = dev(g["x"]), dev(g["dy"])
+    co = P["body.0.weight"].shape[0]
+    # forward
+    y1 = ops.conv3x3(x, ops.pack_conv3x3(P["body.0.weight"]), co)
+    a1, st1, _ = ops.gn_silu_fwd(y1, P["body.1.weight"], P["body.1.bias"])
+    y2 = ops.conv3x3(a1, ops.pack_conv3x3(P["body.3.weight"]), co)
+    a2, st2, pooled = ops.gn_silu_fwd(y2, P["body.4.weight"], P["body.4.bias"], want_pooled=True)
+    z, s = ops.se_excite_fwd(pooled, P["se.fc.0.weight"], P["se.fc.2.weight"])
+    out, fmap, gate = ops.spatial_gate_fwd(a2, s, P["spat.conv.weight"])
+    assert rel_l2(out, g["y"]) < TOL
+    # backward
+    G = {k: torch.zeros_like(v) for k, v in P.items()}
+    dmap, cnt, dpool = ops.gates_bwd(dy, a2, s, z, pooled, gate, fmap, P["se.fc.0.weight"], P["se.fc.2.weight"],
+                                     P["spat.conv.weight"], G["se.fc.0.weight"], G["se.fc.2.weight"],
+                                     G["spat.conv.weight"])
+    dy2 = ops.gn_silu_bwd_gated(y2, P["body.4.weight"], P["body.4.bias"], st2, a2, dy, gate, dmap, fmap, cnt, s, dpool,
+                                G["body.4.weight"], G["body.4.bias"])
+    gw = torch.zeros(co, 9, co, device="cuda")
+    ops.wgrad3x3(a1, dy2, gw)
+    G["body.3.weight"] = ops.wgrad3x3_unpack(gw)
+    da1 = ops.conv3x3(dy2, ops.pack_conv3x3(P["body.3.weight"], dgrad=True), co)
+    dy1 = ops.gn_silu_bwd(y1, P["body.1.weight"], P["body.1.bias"], st1, da1, G["body.1.weight"], G["body.1.bias"])
+    ci = x.shape[1]
+    gw = torch.zeros(co, 9, ci, device="cuda")
+    ops.wgrad3x3(x, dy1, gw)
+    G["body.0.weight"] = ops.wgrad3x3_unpack(gw)
+    dx = ops.conv3x3(dy1, ops.pack_conv3x3(P["body.0.weight"], dgrad=True), ci)
+    assert rel_l2(dx, g["dx"]) < TOL
+    for k in G:
+        assert rel_l2(G[k], g["g." + k]) < TOL, k
+
+
+def test_gates_ties_backward(ops):
+    """SpatialGate backward with exact amax ties (gradient split 1/count), fixture from the reference."""
+    g = load_golden("spatial_gate.npz")
+    x, dy, w7 = g["x"], g["dy"], g["w7"]
+    n, c, h, w = x.shape
+    # SE with W2 = 0 gives s = 0.5 exactly; feed 2x so that U = x bit-exactly
+    w1 = torch.zeros(1, c, 1, 1); w2 = torch.zeros(c, 1, 1, 1)
+    a2 = 2.0 * x
+    pooled = a2.mean((2, 3))
+    z, s = ops.se_excite_fwd(dev(pooled), dev(w1), dev(w2))
+    assert torch.all(s == 0.5)
+    out, fmap, gate = ops.spatial_gate_fwd(dev(a2), s, dev(w7))
+    assert rel_l2(out, g["y"]) < TOL
+    dw1 = torch.zeros_like(dev(w1)); dw2 = torch.zeros_like(dev(w2)); dw7 = torch.zeros_like(dev(w7))
+    dmap, cnt, dpool = ops.gates_bwd(dev(dy), dev(a2), s, z, dev(pooled), gate, fmap, dev(w1), dev(w2), dev(w7), dw1,
+                                     dw2, dw7)
+    assert rel_l2(dw7, g["dw7"]) < TOL
+    # identity "GroupNorm": use gn bwd gated with a real GN whose output we then compare through autograd instead;
+    # here check dU directly: dU = dout*gate + da/C + dm*[U==max]/cnt  -> dx_ref = dU (since U = x)
+    U = dev(x)
+    dU = dev(dy) * gate[:, None] + dmap[:, 0:1] / c + dmap[:, 1:2] * (U == fmap[:, 1:2]).float() / cnt[:, None]
+    assert rel_l2(dU, g["dx"]) < TOL
+    assert cnt.max().item() == c and cnt.min().item() == 1
+
+
+# --------------------------------------------------------------------------------------------- pool / mean / convT
+def test_maxpool_golden_and_skip(ops):
+    g = load_golden("maxpool.npz")
+    y = ops.maxpool2_fwd(dev(g["x"]))
+    assert torch.equal(y.cpu(), g["y"])
+    dx = ops.maxpool2_bwd(dev(g["x"]), dev(g["dy"]))
+    assert torch.equal(dx.cpu(), g["dx"])
+    # fused skip gradient: x is [B*T,...], dskip [B,...]
+    b, t = 1, 2
+    dskip = rnd(b, 4, 8, 12, seed=30)
+    dx2 = ops.maxpool2_bwd(dev(g["x"]), dev(g["dy"]), dev(dskip), t=t)
+    ref = g["dx"] + dskip.repeat_interleave(t, 0) / t
+    assert rel_l2(dx2, ref) < 1e-6
+
+
+def test_time_mean(ops):
+    b, t = 3, 5
+    x = rnd(b * t, 4, 6, 10, seed=31)
+    y = ops.time_mean(dev(x), b, t)
+    assert rel_l2(y, x.reshape(b, t, 4, 6, 10).mean(1)) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 16, 6, 9), (3, 20, 12, 12, 18), (1, 64, 32, 24, 36)])
+def test_convT2x2(ops, shape):
+    n, ci, co, h, w = shape
+    x = rnd(n, ci, h, w, seed=32); wt = rnd(ci, co, 2, 2, seed=33, scale=ci ** -0.5); b = rnd(co, seed=34)
+    dy = rnd(n, co, 2 * h, 2 * w, seed=35)
+    xd = x.double().requires_grad_(); wd = wt.double().requires_grad_(); bd = b.double().requires_grad_()
+    ref = F.conv_transpose2d(xd, wd, bd, stride=2); ref.backward(dy.double())
+    y = ops.convT2x2_fwd(dev(x), dev(wt), dev(b))
+    assert rel_l2(y, ref) < TOL
+    dw = torch.zeros_like(dev(wt)); db = torch.zeros_like(dev(b))
+    dx = ops.convT2x2_bwd(dev(x), dev(wt), dev(dy), dw, db)
+    assert rel_l2(dx, xd.grad) < TOL and rel_l2(dw, wd.grad) < TOL and rel_l2(db, bd.grad) < TOL
+
+
+# --------------------------------------------------------------------------------------------- ConvLSTM pointwise
+def test_lstm_gates(ops):
+    b, ch, h, w = 3, 8, 6, 9
+    pre = rnd(b, 4 * ch, h, w, seed=40); cp = rnd(b, ch, h, w, seed=41)
+    dh = rnd(b, ch, h, w, seed=42); dc_in = rnd(b, ch, h, w, seed=43)
+    pd = pre.double().requires_grad_(); cpd = cp.double().requires_grad_()
+    i, f, o, gg = pd.chunk(4, 1)
+    i, f, o, gg = torch.sigmoid(i), torch.sigmoid(f), torch.sigmoid(o), torch.tanh(gg)
+    cn = f * cpd + i * gg; hn = o * torch.tanh(cn)
+    (hn * dh.double()).sum().backward(retain_graph=True)
+    (cn * dc_in.double()).sum().backward()
+    gates = dev(pre).clone(); c_out = torch.empty(b, ch, h, w, device="cuda"); h_out = torch.empty_like(c_out)
+    ops.lstm_gates_fwd(gates, dev(cp), c_out, h_out)
+    assert rel_l2(c_out, cn) < TOL and rel_l2(h_out, hn) < TOL
+    dc = dev(dc_in).clone()
+    ops.lstm_gates_bwd(gates, dev(cp), c_out, dev(dh), None, dc, first=False)
+    assert rel_l2(gates, pd.grad) < TOL and rel_l2(dc, cpd.grad) < TOL
+
+
+# --------------------------------------------------------------------------------------------- head / loss / adam
+def test_head_and_mse(ops):
+    n, c, oc, h, w = 3, 16, 2, 16, 24
+    x = rnd(n, c, h, w, seed=50); wt = rnd(oc, c, 1, 1, seed=51, scale=0.3); b = rnd(oc, seed=52); y = rnd(n, oc, h, w, seed=53)
+    xd = x.double().requires_grad_(); wd = wt.double().requires_grad_(); bd = b.double().requires_grad_()
+    pr = F.conv2d(xd, wd, bd); ls = F.mse_loss(pr, y.double()); ls.backward()
+    pred = ops.head_fwd(dev(x), dev(wt), dev(b))
+    loss, dpred = ops.mse_loss(pred, dev(y))
+    assert rel_l2(pred, pr) < TOL and abs(loss.item() - ls.item()) < 1e-5 * ls.item()
+    dw = torch.zeros_like(dev(wt)); db = torch.zeros_like(dev(b))
+    dx = ops.head_bwd(dpred, dev(x), dev(wt), dw, db)
+    assert rel_l2(dx, xd.grad) < TOL and rel_l2(dw, wd.grad) < TOL and rel_l2(db, bd.grad) < TOL
+
+
+def test_adam_matches_torch(ops):
+    n = 10007 * 4
+    p = rnd(n, seed=60); g1 = rnd(n, seed=61); g2 = rnd(n, seed=62) * 0.1
+    ref = p.clone().requires_grad_()
+    opt = torch.optim.Adam([ref], lr=5e-4)
+    pd, m, v = dev(p), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step, g in enumerate((g1, g2, g1), 1):
+        ref.grad = g.clone(); opt.step()
+        ops.adam_step(pd, dev(g), m, v, step, 5e-4)
+    assert rel_l2(pd, ref.detach()) < 1e-6
