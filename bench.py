@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training samples/s of unet_convlstm_attention (BASELINE.json configs[1]) on N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N>1: launched by torch.distributed.run)
+
+One "step" = zero grads -> forward -> MSE -> backward -> (RCCL all-reduce) -> Adam on one synthetic batch of
+[32, 6, 5, 48, 72] per GPU (weak scaling), fp32, inputs resident in HBM.  Rank 0 prints ONE JSON line.
+Extra objects: "roofline" (dominant kernel = the fp32-MFMA conv3x3 implicit GEMM, timed with HIP events on the launch
+stream in a second, eager pass over the same workload) and "cpu_baseline" (the CPU oracle's full training step on
+this box's host cores; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: Peak FP32 (matrix), dense
+PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak BW
+
+
+def train_flops_per_sample(b, T, H, W, cin=5, cout=2):
+    """SURVEY.md 8(d) / Appendix C cost model: conv MACs x2, training = 3 x forward."""
+    HW = [H * W, H * W // 4, H * W // 16, H * W // 64]
+    ch = [b, 2 * b, 4 * b, 8 * b]
+    blk = lambda ci, co, hw: 18 * hw * co * (ci + co)
+    enc = blk(cin, b, HW[0]) + sum(blk(ch[i - 1], ch[i], HW[i]) for i in (1, 2, 3))
+    Cx, Ch, hw = 8 * b, 4 * b, HW[3]
+    lstm = 18 * hw * (Cx + Ch) * 4 * Ch
+    up = lambda ci, cs, co, hwo: blk(co + cs, co, hwo) + 8 * ci * co * (hwo // 4)
+    dec = up(4 * b, 4 * b, 4 * b, HW[2]) + up(4 * b, 2 * b, 2 * b, HW[1]) + up(2 * b, b, b, HW[0])
+    head = 2 * b * cout * HW[0]
+    return 3 * (T * enc + T * lstm + dec + head)
+
+
+def cpu_baseline(cfg, steps=5):
+    """Full training step of the CPU oracle (a port of the reference's path) on this box's host cores."""
+    import oracle
+    B, T, C, H, W, base = cfg["B"], cfg["T"], cfg["C"], cfg["H"], cfg["W"], cfg["base"]
+    torch.manual_seed(42)
+    P = {k: v.clone().requires_grad_() for k, v in oracle.closed_form_params(C, 2, base).items()}
+    gen = torch.Generator("cpu").manual_seed(1234)
+    x = torch.randn(B, T, C, H, W, generator=gen)
+    y = torch.randn(B, 2, H, W, generator=gen)
+    opt = torch.optim.Adam([p for p in P.values()], lr=5e-4)
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss = oracle.training_loss(P, x, y)
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    times = sorted(times[1:])
+    med = times[len(times) // 2]
+    return {"value": B / med, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} full training steps (fwd+MSE+bwd+Adam) of the CPU oracle at the same shape "
+                      f"[{B},{T},{C},{H},{W}] base={base} after 1 warm-up; median step {med * 1e3:.0f} ms"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--base", type=int, default=32)
+    ap.add_argument("--seq-len", type=int, default=6)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    from climate_amd import ddp
+    from climate_amd.config import synthetic_config
+    from climate_amd.model import get_model
+    from climate_amd.profiler import KernelTimer
+    from climate_amd.trainer import HotPathTrainer
+    import torch.distributed as dist
+
+    rank, local, world = ddp.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    B, T, C, H, W, base = args.batch, args.seq_len, 5, 48, 72, args.base
+    cfg = synthetic_config(base_channels=base, seq_len=T)
+    torch.manual_seed(cfg.seed)
+    model = get_model(cfg).to(dev)
+    gen = torch.Generator("cpu").manual_seed(1234 + rank)
+    x = torch.randn(B, T, C, H, W, generator=gen).to(dev)
+    y = torch.randn(B, 2, H, W, generator=gen).to(dev)
+    tr = HotPathTrainer(model, lr=cfg.training.lr, weight_decay=cfg.training.weight_decay,
+                        use_graph=not args.no_graph)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.step(x, y)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tr.step(x, y)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    final_loss = loss.item()
+
+    # ---- roofline pass: same workload, eager launches, HIP events around every launcher --------------------------
+    roof, kernels = None, {}
+    if rank == 0:
+        tr_e = tr
+        tr_e.use_graph = False
+        with KernelTimer() as kt:
+            for _ in range(args.profile_steps):
+                tr_e._fwd_bwd(x, y)
+                tr_e._adam()
+        summ = kt.summary()
+        for name, d in summ.items():
+            kernels[name] = {"calls_per_step": d["calls"] / args.profile_steps,
+                             "ms_per_step": round(d["ms"] / args.profile_steps, 4)}
+            if d["flops"]:
+                kernels[name]["tflops"] = round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2)
+            if d["bytes"] and not d["flops"]:
+                kernels[name]["gbps"] = round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1)
+        c = summ.get("cm_conv3x3")
+        if c:
+            ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
+            roof = {"kernel": "conv3x3_mfma_kernel (cm_conv3x3: forward + data-gradient launches)", "bound": "mfma",
+                    "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": c["calls"] / args.profile_steps,
+                    "avg_launch_us": round(c["ms"] * 1e3 / c["calls"], 2)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(dict(B=B, T=T, C=C, H=H, W=W, base=base))
+
+    if rank == 0:
+        gb = B * world
+        value = gb * args.steps / dt
+        fl = train_flops_per_sample(base, T, H, W)
+        out = {
+            "metric": "training samples/sec (seq_len=6, 48x72 grid)", "value": round(value, 2), "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"unet_convlstm_attention base={base} seq_len={T} 48x72 5->2, "
+                                   f"per-GPU batch {B} (BASELINE.json configs[1]), fwd+MSE+bwd+all-reduce+Adam",
+                       "global_batch": gb, "seq_len": T, "parallelism": f"dp{world}",
+                       "hip_graph": not args.no_graph},
+            "step_mfma_frac": round(value / world * fl / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+            "final_loss": final_loss,
+            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

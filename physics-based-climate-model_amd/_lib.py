@@ -6,6 +6,11 @@ import ctypes
 import os
 import re
 
+# torch bundles its own HIP runtime (torch/lib/libamdhip64.so).  It must be in the process BEFORE libclimate_hip.so
+# is dlopen'ed so that our NEEDED libamdhip64.so.7 resolves to that same runtime instance; loaded the other way round
+# the process ends up with two runtimes and every launch fails with hipErrorNoDevice.
+import torch  # noqa: F401  (device memory / streams come from torch anyway)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(_ROOT, "include", "climate_hip.h")
@@ -78,8 +83,16 @@ class _Lib:
 
     def __getattr__(self, name):
         if name.startswith("cm_"):
-            return getattr(self.load(), name)
+            fn = getattr(self.load(), name)
+            hook = self.__dict__.get("_hook")
+            if hook is not None:
+                return hook.wrap(name, fn)
+            return fn
         raise AttributeError(name)
+
+    def set_hook(self, hook):
+        """Install (or clear, with None) a launch hook: an object with wrap(name, fn) -> callable (see profiler.py)."""
+        self.__dict__["_hook"] = hook
 
 
 lib = _Lib()

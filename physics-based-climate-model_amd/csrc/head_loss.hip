@@ -29,6 +29,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     if (o < OC) pred[((long long)n * OC + o) * HW + p] = acc[o];
 }
 
+__global__ void zero1_kernel(float* p) { *p = 0.f; }
+
 // loss += sum (pred-y)^2 / total ; dpred = 2 (pred - y) / total
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred, const float* __restrict__ y,
                                                    float* __restrict__ loss, float* __restrict__ dpred,
@@ -103,8 +105,8 @@ int cm_head_fwd(const float* x, long long sx, const float* w, const float* b, fl
 
 int cm_mse_loss(const float* pred, const float* y, float* loss, float* dpred, long long total, cm_stream stream) {
   if (total <= 0) return -22;
-  hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream);
-  if (e != hipSuccess) return (int)e;
+  zero1_kernel<<<1, 1, 0, (hipStream_t)stream>>>(loss);   // a kernel node, not a memset node (see cm_zero)
+  CM_CHECK_LAUNCH();
   long long blocks = (total + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   mse_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(pred, y, loss, dpred, total);

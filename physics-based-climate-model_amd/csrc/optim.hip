@@ -55,6 +55,23 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   for (long long i = n4 * 4 + t0; i < n; i += stride) upd(p[i], g[i], m[i], v[i]);
 }
 
+// Zero-fill as a kernel, not hipMemsetAsync: a captured hipMemsetAsync node was observed (ROCm 7.0 runtime bundled
+// with torch, MI355X) to clear memory beyond its range on hipGraph replay; a kernel node replays exactly.
+__global__ void zero_kernel(uint32_t* __restrict__ p, size_t words, unsigned char* __restrict__ tail, int tail_bytes) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t t0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const size_t w4 = words / 4;
+  uint4* p4 = reinterpret_cast<uint4*>(p);
+  const bool aligned = ((size_t)p & 15) == 0;
+  if (aligned) {
+    for (size_t i = t0; i < w4; i += stride) p4[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (size_t i = w4 * 4 + t0; i < words; i += stride) p[i] = 0u;
+  } else {
+    for (size_t i = t0; i < words; i += stride) p[i] = 0u;
+  }
+  if (t0 < (size_t)tail_bytes) tail[t0] = 0;
+}
+
 __global__ void scale_kernel(float* __restrict__ x, long long n, float s) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
     x[i] *= s;
@@ -110,7 +127,15 @@ int cm_scale(float* x, long long n, float s, cm_stream stream) {
 
 int cm_zero(void* p, size_t bytes, cm_stream stream) {
   if (bytes == 0) return 0;
-  return (int)hipMemsetAsync(p, 0, bytes, (hipStream_t)stream);
+  if ((size_t)p & 3) return -22;
+  const size_t words = bytes / 4;
+  const int tail = (int)(bytes % 4);
+  size_t blocks = (words / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  zero_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>((uint32_t*)p, words, (unsigned char*)p + words * 4, tail);
+  CM_CHECK_LAUNCH();
+  return 0;
 }
 
 }  // extern "C"

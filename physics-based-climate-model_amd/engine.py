@@ -73,19 +73,32 @@ def _block_bwd(p: Params, pk, g: Params, prefix: str, ctx: _BlockCtx, dout: Tens
     dy2 = ops.gn_silu_bwd_gated(ctx.y2, p[prefix + "body.4.weight"], p[prefix + "body.4.bias"], ctx.st2, ctx.a2, dout,
                                 ctx.gate, dmap, ctx.fmap, cnt, ctx.s, dpool, g[prefix + "body.4.weight"],
                                 g[prefix + "body.4.bias"])
-    gw = torch.zeros(co, 9, co, device=dout.device, dtype=torch.float32)
+    gw = _zeros(co, 9, co, device=dout.device)
     ops.wgrad3x3(ctx.a1, dy2, gw)
     _unpack_into(gw, g[prefix + "body.3.weight"])
     da1 = ops.conv3x3(dy2, pk[prefix + "body.3.weight/d"], co)
     dy1 = ops.gn_silu_bwd(ctx.y1, p[prefix + "body.1.weight"], p[prefix + "body.1.bias"], ctx.st1, da1,
                           g[prefix + "body.1.weight"], g[prefix + "body.1.bias"])
     ci = ctx.x0.shape[1] + (0 if ctx.x1 is None else ctx.x1.shape[1])
-    gw = torch.zeros(co, 9, ci, device=dout.device, dtype=torch.float32)
+    gw = _zeros(co, 9, ci, device=dout.device)
     ops.wgrad3x3(ctx.x0, dy1, gw, x1=ctx.x1)
     _unpack_into(gw, g[prefix + "body.0.weight"])
     if not need_dx:
         return None
     return ops.conv3x3(dy1, pk[prefix + "body.0.weight/d"], ci)
+
+
+def _zeros(*shape, device) -> Tensor:
+    """Zero-filled scratch via hipMemsetAsync on the current stream (a memset node under graph capture)."""
+    from ._lib import check, lib
+    t = torch.empty(*shape, device=device, dtype=torch.float32)
+    check(lib.cm_zero(t.data_ptr(), t.numel() * 4, torch.cuda.current_stream().cuda_stream), "zero")
+    return t
+
+
+def _zero_(t: Tensor) -> None:
+    from ._lib import check, lib
+    check(lib.cm_zero(t.data_ptr(), t.numel() * 4, torch.cuda.current_stream().cuda_stream), "zero")
 
 
 def _unpack_into(gw: Tensor, dst: Tensor) -> None:
@@ -128,8 +141,7 @@ def forward(p: Params, pk, x_seq: Tensor, save: bool = True):
     ch = wl.shape[0] // 4
     h8, w8 = H // 8, W // 8
     gx = ops.conv3x3(s4, pk["lstm.x/f"], 4 * ch, bias=bl).view(B, T, 4 * ch, h8, w8)
-    hprev = torch.empty(B, T, ch, h8, w8, device=x.device, dtype=torch.float32)
-    hprev[:, 0].zero_()
+    hprev = _zeros(B, T, ch, h8, w8, device=x.device)       # hprev[:, t] = h_{t-1}; slot 0 stays 0
     call = torch.empty(B, T, ch, h8, w8, device=x.device, dtype=torch.float32)
     bott = torch.empty(B, ch, h8, w8, device=x.device, dtype=torch.float32)
     for t in range(T):
@@ -191,7 +203,7 @@ def backward(p: Params, pk, g: Params, sv: Saved, dpred: Tensor, need_dx: bool =
         if t > 0:
             dhrec = ops.conv3x3(gx[:, t], pk["lstm.h/d"], ch)
     dA = gx.view(B * T, 4 * ch, h8, w8)            # now holds d(pre-activations) for every (b, t)
-    gw = torch.zeros(4 * ch, 9, cx + ch, device=dpred.device, dtype=torch.float32)
+    gw = _zeros(4 * ch, 9, cx + ch, device=dpred.device)
     ops.wgrad3x3(sv.s4, dA, gw, c_off=0)
     if T > 1:
         ops.wgrad3x3(hprev.view(B * T, ch, h8, w8), dA, gw, c_off=cx)   # hprev[:, 0] == 0 contributes nothing

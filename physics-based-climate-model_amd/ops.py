@@ -23,6 +23,40 @@ def _p(t):
     return t.data_ptr()
 
 
+# --------------------------------------------------------------------------------------------------- autotuning
+# Tile configurations are chosen empirically per call signature the first time it is seen outside graph capture
+# (3 timed launches per configuration into scratch outputs); the choice is cached for the life of the process.
+AUTOTUNE = True
+_TUNED = {}
+
+
+def _pick(key, n_cfg, launch, fallback):
+    """launch(cfg) enqueues one launch with that configuration into scratch memory."""
+    if key in _TUNED:
+        return _TUNED[key]
+    if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
+        return fallback
+    best, best_t = fallback, float("inf")
+    for cfg in range(n_cfg):
+        launch(cfg)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            launch(cfg)
+        e1.record()
+        e1.synchronize()
+        t = e0.elapsed_time(e1)
+        if t < best_t:
+            best, best_t = cfg, t
+    _TUNED[key] = best
+    return best
+
+
+def tuned_table():
+    return dict(_TUNED)
+
+
 def _contig(t):
     if not t.is_contiguous():
         raise RuntimeError("climate_hip ops need contiguous tensors")
@@ -48,7 +82,15 @@ def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1):
     for t in (x0, x1, out, resid):
         if t is not None and (t.stride(3) != 1 or t.stride(2) != w or t.stride(1) != h * w):
             raise RuntimeError("conv3x3 needs dense HxW planes with channel stride H*W")
-    check(lib.cm_conv3x3(_p(x0), x0.stride(0), c0, _p(x1), 0 if x1 is None else x1.stride(0), c1, _p(wp), _p(bias),
+    st1 = 0 if x1 is None else x1.stride(0)
+    if config < 0:
+        def launch(cfg, _scratch=[None]):
+            if _scratch[0] is None:
+                _scratch[0] = torch.empty(n, cout, h, w, device=x0.device, dtype=torch.float32)
+            check(lib.cm_conv3x3(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(wp), _p(bias), None, 0,
+                                 _p(_scratch[0]), _scratch[0].stride(0), n, h, w, cout, cfg, _stream()), "conv3x3 tune")
+        config = _pick(("conv3x3", n, h, w, c0, c1, cout), lib.cm_conv3x3_num_configs(), launch, -1)
+    check(lib.cm_conv3x3(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(wp), _p(bias),
                          _p(resid), 0 if resid is None else resid.stride(0), _p(out), out.stride(0), n, h, w, cout,
                          config, _stream()), "conv3x3")
     return out
@@ -59,7 +101,15 @@ def wgrad3x3(x0, dy, g, c_off=0, x1=None, config=-1):
     n, c0, h, w = x0.shape
     c1 = 0 if x1 is None else x1.shape[1]
     cout, ctot = g.shape[0], g.shape[2]
-    check(lib.cm_wgrad3x3(_p(x0), x0.stride(0), c0, _p(x1), 0 if x1 is None else x1.stride(0), c1, _p(dy),
+    st1 = 0 if x1 is None else x1.stride(0)
+    if config < 0:
+        def launch(cfg, _scratch=[None]):
+            if _scratch[0] is None:
+                _scratch[0] = torch.empty_like(g)
+            check(lib.cm_wgrad3x3(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(dy), dy.stride(0), _p(_scratch[0]),
+                                  ctot, c_off, n, h, w, cout, cfg, _stream()), "wgrad3x3 tune")
+        config = _pick(("wgrad3x3", n, h, w, c0, c1, cout), lib.cm_wgrad3x3_num_configs(), launch, -1)
+    check(lib.cm_wgrad3x3(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(dy),
                           dy.stride(0), _p(g), ctot, c_off, n, h, w, cout, config, _stream()), "wgrad3x3")
     return g
 

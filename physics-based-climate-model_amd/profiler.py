@@ -1,0 +1,88 @@
+"""Per-launch HIP-event timing of the ``cm_*`` launchers (used by bench.py for the roofline figures).
+
+Events are recorded on the stream each kernel is launched on (torch's current stream, whose handle is what the
+launchers receive), immediately before and after the launch.  Algorithmic flops / bytes are derived from the launch
+arguments, not from counters.
+"""
+import collections
+
+import torch
+
+
+def _conv_flops(a):        # cm_conv3x3(in0, st0, c0, in1, st1, c1, wp, bias, resid, st_resid, out, st_out, n, h, w, cout, ..)
+    return 2.0 * a[12] * a[13] * a[14] * a[15] * (a[2] + a[5]) * 9
+
+
+def _conv_bytes(a):
+    n, h, w, cout, cin = a[12], a[13], a[14], a[15], a[2] + a[5]
+    return 4.0 * (n * h * w * (cin + cout) + 9 * cin * cout)
+
+
+def _wgrad_flops(a):       # cm_wgrad3x3(x0, sx0, c0, x1, sx1, c1, dy, sdy, g, ctot, c_off, n, h, w, cout, config, stream)
+    return 2.0 * a[11] * a[12] * a[13] * a[14] * (a[2] + a[5]) * 9
+
+
+def _wgrad_bytes(a):
+    n, h, w, cout, cin = a[11], a[12], a[13], a[14], a[2] + a[5]
+    return 4.0 * (n * h * w * (cin + cout) + 9 * cin * cout)
+
+
+def _lstm_fwd_bytes(a):    # (gates, sg, c_prev, scp, c_out, sco, h_out, sho, b, ch, hw, stream)
+    return 4.0 * a[8] * a[9] * a[10] * (4 + (1 if a[2] else 0) + 4 + 2)
+
+
+def _lstm_bwd_bytes(a):    # (gates, sg, c_prev, scp, c_cur, scc, dh_a, sa, dh_b, sb, dc, first, b, ch, hw, stream)
+    reads = 4 + (1 if a[2] else 0) + 1 + (1 if a[6] else 0) + (1 if a[8] else 0) + (0 if a[11] else 1)
+    return 4.0 * a[12] * a[13] * a[14] * (reads + 5)
+
+
+MODELS = {
+    "cm_conv3x3": (_conv_flops, _conv_bytes),
+    "cm_wgrad3x3": (_wgrad_flops, _wgrad_bytes),
+    "cm_lstm_gates_fwd": (None, _lstm_fwd_bytes),
+    "cm_lstm_gates_bwd": (None, _lstm_bwd_bytes),
+}
+
+
+class KernelTimer:
+    """with KernelTimer() as kt: ...launches...; kt.summary() -> {name: dict(calls, ms, flops, bytes)}"""
+
+    def __init__(self):
+        self.records = []
+
+    def wrap(self, name, fn):
+        if name in ("cm_version", "cm_arch") or "pick_config" in name or "num_configs" in name or "packed_elems" in name:
+            return fn
+
+        def timed(*a):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            st = torch.cuda.current_stream()
+            e0.record(st)
+            rc = fn(*a)
+            e1.record(st)
+            fl, by = MODELS.get(name, (None, None))
+            self.records.append((name, e0, e1, fl(a) if fl else 0.0, by(a) if by else 0.0))
+            return rc
+        return timed
+
+    def __enter__(self):
+        from ._lib import lib
+        lib.set_hook(self)
+        return self
+
+    def __exit__(self, *exc):
+        from ._lib import lib
+        lib.set_hook(None)
+        return False
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = collections.OrderedDict()
+        for name, e0, e1, fl, by in self.records:
+            d = out.setdefault(name, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["calls"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+            d["bytes"] += by
+        return out

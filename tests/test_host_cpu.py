@@ -1,0 +1,126 @@
+"""CPU-side checks: the C-ABI library loads and exports everything include/climate_hip.h declares, the drop-in module
+has the reference's exact parameter inventory and default init, the factory / config surface behaves like the
+reference's, and the product path refuses to run without the GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import load_golden
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    from climate_amd._lib import lib, parse_header, LIB_PATH
+    assert os.path.exists(LIB_PATH), "build with python physics-based-climate-model_amd/build.py"
+    protos = parse_header()
+    assert len(protos) >= 37
+    dll = lib.load()
+    for name in protos:
+        assert hasattr(dll, name), name
+    assert lib.cm_version() == 1 and lib.cm_arch() == b"gfx950"
+    # pure host-side helpers work without a GPU
+    assert lib.cm_conv3x3_packed_elems(5, 32) == 8 * 9 * 32
+    assert 0 <= lib.cm_conv3x3_pick_config(192, 48, 72, 32) < lib.cm_conv3x3_num_configs()
+    assert 0 <= lib.cm_wgrad3x3_pick_config(192, 6, 9, 256) < lib.cm_wgrad3x3_num_configs()
+
+
+def test_cabi_argument_errors_are_reported_not_crashed():
+    from climate_amd._lib import lib
+    assert lib.cm_conv3x3(None, 0, 0, None, 0, 0, None, None, None, 0, None, 0, 0, 8, 8, 8, -1, None) == -22
+    assert lib.cm_gn_silu_fwd(None, None, None, None, None, None, 2, 12, 64, 8, 1e-5, None) == -22   # 12 % 8 != 0
+    assert lib.cm_maxpool2_fwd(None, None, 4, 7, 8, None) == -22                                   # odd height
+    assert lib.cm_head_fwd(None, 0, None, None, None, 1, 8, 9, 64, None) == -22                     # out_ch > 8
+
+
+@pytest.mark.parametrize("base,in_ch", [(8, 5), (16, 7), (32, 5)])
+def test_state_dict_matches_reference_inventory(base, in_ch):
+    from climate_amd.model import AttUNetConvLSTM
+    m = AttUNetConvLSTM(in_ch=in_ch, out_ch=2, base=base, seq_len=6)
+    want = oracle.param_shapes(in_ch, 2, base)
+    sd = m.state_dict()
+    assert list(sd) == list(want) and len(sd) == 75
+    for k, s in want.items():
+        assert tuple(sd[k].shape) == s
+    assert [n for n, _ in m.named_parameters()] == list(want)
+    assert len(m._grad_names) == 73 and not any(n.startswith("post_conv") for n in m._grad_names)
+
+
+def test_default_init_equals_reference_under_seed():
+    """torch.manual_seed(42) + construction consumes the RNG exactly like the reference's __init__ does."""
+    from climate_amd.model import AttUNetConvLSTM
+    g = load_golden("init_seed42_base32.npz")
+    torch.manual_seed(42)
+    m = AttUNetConvLSTM(in_ch=5, out_ch=2, base=32, seq_len=6)
+    sd = m.state_dict()
+    assert list(sd) == g["names"].tolist()
+    for k, s, f in zip(g["names"].tolist(), g["sums"].tolist(), g["firsts"]):
+        assert abs(sd[k].double().sum().item() - s) < 1e-9, k
+        n = min(4, sd[k].numel())
+        assert np.allclose(sd[k].flatten()[:n].double().numpy(), np.asarray(f)[:n], atol=0)
+
+
+def test_reference_checkpoint_layout_loads_both_ways():
+    from climate_amd.model import AttUNetConvLSTM
+    p = oracle.closed_form_params(5, 2, 8)
+    m = AttUNetConvLSTM(5, 2, 8)
+    missing = m.load_state_dict(p, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    flat = m.flatten_parameters_()
+    assert flat.numel() >= sum(v.numel() for v in p.values())
+    for k, v in m.state_dict().items():                 # values survive flattening, views alias the flat buffer
+        assert torch.equal(v, p[k])
+    m.enc1.body[0].weight.data.add_(1.0)
+    assert torch.equal(flat[:m.enc1.body[0].weight.numel()].view_as(p["enc1.body.0.weight"]),
+                       p["enc1.body.0.weight"] + 1.0)
+    # Lightning prefixes keys with "model."
+    from climate_amd.lightning_module import ClimateEmulationModule
+    lm = ClimateEmulationModule(AttUNetConvLSTM(5, 2, 8), learning_rate=5e-4, weight_decay=0.0)
+    assert all(k.startswith("model.") for k in lm.state_dict())
+    assert len(lm.state_dict()) == 75
+
+
+def test_factory_and_config_surface():
+    import climate_amd
+    from climate_amd.config import load_config, synthetic_config
+    from climate_amd.model import AttUNetConvLSTM, get_model
+    cfg = load_config(os.path.join(climate_amd._PKG_DIR, "configs"),
+                      overrides=["model.base_channels=16", "training.lr=1e-3", "trainer.devices=8"])
+    assert cfg.model.type == "unet_convlstm_attention" and cfg.model.base_channels == 16
+    assert cfg.training.lr == 1e-3 and cfg.training.weight_decay == 0 and cfg.trainer.devices == 8 and cfg.seed == 42
+    m = get_model(cfg)
+    assert isinstance(m, AttUNetConvLSTM) and m.in_ch == 5 and m.out_ch == 2 and m.base == 16 and m.seq_len == 6
+    cfg.model["in_ch"] = 7                               # the reference's hard-coded value, opt-in
+    assert get_model(cfg).in_ch == 7
+    cfg.model["type"] = "does_not_exist"
+    with pytest.raises(ValueError, match="Unknown model type: does_not_exist"):
+        get_model(cfg)
+    cfg.model["type"] = "SimpleCNN"
+    with pytest.raises(NotImplementedError):
+        get_model(cfg)
+    assert get_model(synthetic_config(base_channels=32)).base == 32
+
+
+def test_product_path_has_no_cpu_fallback():
+    from climate_amd.model import AttUNetConvLSTM
+    from climate_amd import ops
+    m = AttUNetConvLSTM(5, 2, 8)
+    with pytest.raises(RuntimeError, match="HIP path only"):
+        m(torch.zeros(1, 2, 5, 8, 8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.maxpool2_fwd(torch.zeros(1, 1, 4, 4))
+
+
+def test_lightning_module_surface():
+    from climate_amd.lightning_module import ClimateEmulationModule
+    from climate_amd.model import AttUNetConvLSTM
+    from climate_amd.optim import HipAdam
+    lm = ClimateEmulationModule(AttUNetConvLSTM(5, 2, 8), learning_rate=5e-4, weight_decay=0.0)
+    opt = lm.configure_optimizers()
+    assert isinstance(opt, HipAdam) and isinstance(opt, torch.optim.Optimizer)
+    g = opt.param_groups[0]
+    assert g["lr"] == 5e-4 and g["betas"] == (0.9, 0.999) and g["eps"] == 1e-8 and g["weight_decay"] == 0.0
+    assert len(g["params"]) == 75
+    for name in ("forward", "training_step", "configure_optimizers"):
+        assert callable(getattr(lm, name))

@@ -321,3 +321,35 @@ def test_adam_matches_torch(ops):
         ref.grad = g.clone(); opt.step()
         ops.adam_step(pd, dev(g), m, v, step, 5e-4)
     assert rel_l2(pd, ref.detach()) < 1e-6
+
+
+def test_zero_fill_exact_range_under_graph_replay(ops):
+    """cm_zero is a kernel node: replayed inside a hipGraph it must clear exactly its range (a captured
+    hipMemsetAsync node was seen to clear neighbouring buffers on replay)."""
+    from climate_amd._lib import lib, check
+    buf = torch.ones(3 * 1000 + 5, device="cuda")
+    mid = buf[1000:2003]
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        check(lib.cm_zero(mid.data_ptr(), mid.numel() * 4, s.cuda_stream))
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    buf.fill_(1.0)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        check(lib.cm_zero(mid.data_ptr(), mid.numel() * 4, torch.cuda.current_stream().cuda_stream))
+    buf.fill_(1.0)
+    g.replay(); g.replay()
+    torch.cuda.synchronize()
+    assert buf[:1000].eq(1).all() and buf[2003:].eq(1).all() and mid.eq(0).all()
+
+
+def test_autotune_is_cached_and_correct(ops):
+    ops._TUNED.clear()
+    x = rnd(4, 16, 12, 18, seed=70); wt = rnd(32, 16, 3, 3, seed=71, scale=0.1)
+    wp = ops.pack_conv3x3(dev(wt))
+    y = ops.conv3x3(dev(x), wp, 32)
+    key = ("conv3x3", 4, 12, 18, 16, 0, 32)
+    assert key in ops.tuned_table()
+    assert rel_l2(y, F.conv2d(x.double(), wt.double(), padding=1)) < TOL
