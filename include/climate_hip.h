@@ -45,7 +45,9 @@ int cm_conv3x3(const float* in0, long long st0, int c0, const float* in1, long l
 /* ---- conv3x3 weight gradient ------------------------------------------------------------------------------- *
  * convolution_backward (weight) of the convs above.  Accumulates (fp32 atomics) into a tap-major staging buffer
  * g[cout][9][ctot] that the caller zeroes once per step; cm_wgrad3x3_unpack transposes it to [cout][ctot][3][3].
- * x = cat(x0[:, :c0], x1[:, :c1]) occupies input-channel range [c_off, c_off+c0+c1) of the full weight.          */
+ * x = cat(x0[:, :c0], x1[:, :c1]) occupies input-channel range [c_off, c_off+c0+c1) of the full weight.
+ * config: < 0 automatic; else bits 0-7 = tile configuration, bits 8.. = grid size in quarter rounds of the
+ * resident workgroup slots (0 = one full round).                                                                */
 int cm_wgrad3x3_num_configs(void);
 int cm_wgrad3x3_pick_config(int n, int h, int w, int cout);
 int cm_wgrad3x3(const float* x0, long long sx0, int c0, const float* x1, long long sx1, int c1, const float* dy,

@@ -79,24 +79,34 @@ __global__ __launch_bounds__(256) void se_excite_bwd_kernel(const float* __restr
   }
 }
 
-// dW2[c][r] += sum_n dsig[n,c] relu(z[n,r]);  dW1[r][c] += sum_n dz[n,r] pooled[n,c]   (deterministic: one thread
-// per weight, serial over n)
-__global__ void se_wgrad_kernel(const float* __restrict__ dsig, const float* __restrict__ dz,
-                                const float* __restrict__ z, const float* __restrict__ pooled,
-                                float* __restrict__ dw1, float* __restrict__ dw2, int N, int C, int Cr) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * C * Cr) return;
-  if (i < C * Cr) {  // dW2[c][r]
-    const int c = i / Cr, r = i % Cr;
-    float a = 0.f;
-    for (int n = 0; n < N; ++n) a += dsig[(long long)n * C + c] * fmaxf(z[(long long)n * Cr + r], 0.f);
-    dw2[i] += a;
-  } else {           // dW1[r][c]
-    const int j = i - C * Cr;
-    const int r = j / C, c = j % C;
-    float a = 0.f;
-    for (int n = 0; n < N; ++n) a += dz[(long long)n * Cr + r] * pooled[(long long)n * C + c];
-    dw1[j] += a;
+// dW2[c][r] += sum_n dsig[n,c] relu(z[n,r]);  dW1[r][c] += sum_n dz[n,r] pooled[n,c]
+// 32 weights x 8 sample-slices per workgroup, slices combined through LDS (deterministic order).
+__global__ __launch_bounds__(256) void se_wgrad_kernel(const float* __restrict__ dsig, const float* __restrict__ dz,
+                                                        const float* __restrict__ z,
+                                                        const float* __restrict__ pooled, float* __restrict__ dw1,
+                                                        float* __restrict__ dw2, int N, int C, int Cr) {
+  __shared__ float part[8][33];
+  const int wl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + wl;
+  const int total = 2 * C * Cr;
+  float a = 0.f;
+  if (i < total) {
+    if (i < C * Cr) {  // dW2[c][r]
+      const int c = i / Cr, r = i % Cr;
+      for (int n = sl; n < N; n += 8) a += dsig[(long long)n * C + c] * fmaxf(z[(long long)n * Cr + r], 0.f);
+    } else {           // dW1[r][c]
+      const int j = i - C * Cr;
+      const int r = j / C, c = j % C;
+      for (int n = sl; n < N; n += 8) a += dz[(long long)n * Cr + r] * pooled[(long long)n * C + c];
+    }
+  }
+  part[sl][wl] = a;
+  __syncthreads();
+  if (sl == 0 && i < total) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += part[k][wl];
+    if (i < C * Cr) dw2[i] += t; else dw1[i - C * Cr] += t;
   }
 }
 
@@ -284,7 +294,7 @@ int cm_se_excite_bwd(const float* ds, const float* s, const float* z, const floa
   se_excite_bwd_kernel<<<n, 256, (c + cr) * sizeof(float), (hipStream_t)stream>>>(ds, s, z, w1, w2, dsig, dz, dpool,
                                                                                    c, cr);
   CM_CHECK_LAUNCH();
-  se_wgrad_kernel<<<cdiv(2 * c * cr, 256), 256, 0, (hipStream_t)stream>>>(dsig, dz, z, pooled, dw1, dw2, n, c, cr);
+  se_wgrad_kernel<<<cdiv(2 * c * cr, 32), 256, 0, (hipStream_t)stream>>>(dsig, dz, z, pooled, dw1, dw2, n, c, cr);
   CM_CHECK_LAUNCH();
   return 0;
 }

@@ -91,6 +91,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_mfma_kernel(Conv3Args a) {
 
   float xr[NLX];
   f32x4 wr[NLW];
+  int cvalid_pending = 0;   // channel validity bound of the chunk currently held in xr (applied at LDS-store time)
 
   auto load_chunk = [&](int chunk) {
     const int ch0 = chunk * KC;
@@ -110,21 +111,26 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_mfma_kernel(Conv3Args a) {
       const int e = tid + i * THREADS;
       const int c = e / CS;
       const int off = (DUAL && second) ? goff1[i] : goff0[i];
-      xr[i] = (off >= 0 && c < cvalid) ? src[off] : 0.f;
+      // unconditional load from a clamped (always valid) address; the zero-select happens at LDS-store time so that
+      // nothing consumes the loaded value before the MFMA phase (a select here would force s_waitcnt vmcnt(0))
+      const bool ok = off >= 0 && c < cvalid;
+      xr[i] = src[ok ? off : 0];
     }
+    cvalid_pending = cvalid;
     const float* wsrc = a_wp + (long long)ch0 * 9 * a_CoutP + co0;
 #pragma unroll
     for (int i = 0; i < NLW; ++i) {
-      const int f = tid + i * THREADS;
+      const int f = min(tid + i * THREADS, WN4 - 1);
       const int r = f / (BCO / 4), q4 = f % (BCO / 4);
-      if (f < WN4) wr[i] = *reinterpret_cast<const f32x4*>(wsrc + (long long)r * a_CoutP + 4 * q4);
+      wr[i] = *reinterpret_cast<const f32x4*>(wsrc + r * a_CoutP + 4 * q4);
     }
   };
   auto store_chunk = [&]() {
 #pragma unroll
     for (int i = 0; i < NLX; ++i) {
       const int e = tid + i * THREADS;
-      if (e < XN) Xl[e] = xr[i];
+      const bool ok = goff0[i] >= 0 && (e / CS) < cvalid_pending;   // goff0/goff1 share their validity
+      if (e < XN) Xl[e] = ok ? xr[i] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < NLW; ++i) {
@@ -185,20 +191,49 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_mfma_kernel(Conv3Args a) {
   }
 
   // ---- epilogue: D[i = cout][j = pixel]; lane holds pixel j = l31, rows (r&3) + 8*(r>>2) + 4*half ----
+  // Bias and residual are folded into the accumulators in their own (wave-uniform) blocks first, so that their loads
+  // are issued back to back and the store loop below contains no load: on CDNA4 vmcnt also counts stores, and a
+  // load->use inside the store loop would make every store wait for the previous one.
+  if (a.bias) {
+#pragma unroll
+    for (int m = 0; m < WM; ++m) {
+      float bv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        bv[r] = a.bias[co < a.Cout ? co : 0];
+      }
+#pragma unroll
+      for (int p = 0; p < NPT; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][p][r] += bv[r];
+    }
+  }
+  if (a.resid) {
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+      for (int p = 0; p < NPT; ++p) {
+        float rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const bool ok = pvalid[p] && co < a.Cout;
+          rv[r] = a.resid[ok ? obase[p] + (long long)co * HW : 0];   // same addressing as out (host-checked)
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][p][r] += rv[r];
+      }
+  }
 #pragma unroll
   for (int m = 0; m < WM; ++m) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (co < a.Cout) {
-        const float b = a.bias ? a.bias[co] : 0.f;
+    for (int p = 0; p < NPT; ++p) {
+      if (pvalid[p]) {
 #pragma unroll
-        for (int p = 0; p < NPT; ++p) {
-          if (pvalid[p]) {
-            float v = acc[m][p][r] + b;
-            if (a.resid) v += a.resid[obase[p] + (long long)co * HW];  // same addressing as out (host-checked)
-            a.out[obase[p] + (long long)co * HW] = v;
-          }
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (co < a.Cout) a.out[obase[p] + (long long)co * HW] = acc[m][p][r];
         }
       }
     }

@@ -16,11 +16,8 @@ namespace {
 
 constexpr int GN_THREADS = 256;
 
-__device__ __forceinline__ float silu_f(float u) { return u / (1.f + expf(-u)); }
-__device__ __forceinline__ float silu_grad(float u) {
-  const float sg = 1.f / (1.f + expf(-u));
-  return sg * (1.f + u * (1.f - sg));
-}
+// sigmoid with the hardware exp / rcp (v_exp_f32, v_rcp_f32): ~1e-7 relative, far inside the 1e-4 parity budget
+__device__ __forceinline__ float fast_sigmoid(float u) { return __frcp_rn(1.f + __expf(-u)); }
 
 template <bool VEC>
 __global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_kernel(const float* __restrict__ x,
@@ -38,33 +35,29 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_kernel(const float* __
   float* yg = y + base;
   const int tid = threadIdx.x;
 
-  float s = 0.f;
+  // one statistics pass: sums of (x - pivot) and (x - pivot)^2 with the group's first element as pivot (keeps the
+  // E[d^2] - E[d]^2 cancellation harmless); the apply pass then re-reads the group from L2
+  const float pivot = xg[0];
+  float s1 = 0.f, s2 = 0.f;
   if (VEC) {
     const float4* x4 = reinterpret_cast<const float4*>(xg);
     for (int i = tid; i < L / 4; i += GN_THREADS) {
       const float4 v = x4[i];
-      s += (v.x + v.y) + (v.z + v.w);
-    }
-  } else {
-    for (int i = tid; i < L; i += GN_THREADS) s += xg[i];
-  }
-  const float mean = block_sum(s, red) / (float)L;
-
-  float q = 0.f;
-  if (VEC) {
-    const float4* x4 = reinterpret_cast<const float4*>(xg);
-    for (int i = tid; i < L / 4; i += GN_THREADS) {
-      const float4 v = x4[i];
-      const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
-      q += (a * a + b * b) + (c * c + d * d);
+      const float a = v.x - pivot, b = v.y - pivot, c = v.z - pivot, d = v.w - pivot;
+      s1 += (a + b) + (c + d);
+      s2 += (a * a + b * b) + (c * c + d * d);
     }
   } else {
     for (int i = tid; i < L; i += GN_THREADS) {
-      const float a = xg[i] - mean;
-      q += a * a;
+      const float a = xg[i] - pivot;
+      s1 += a;
+      s2 += a * a;
     }
   }
-  const float var = block_sum(q, red) / (float)L;
+  s1 = block_sum(s1, red) / (float)L;
+  s2 = block_sum(s2, red) / (float)L;
+  const float mean = pivot + s1;
+  const float var = fmaxf(s2 - s1 * s1, 0.f);
   const float rstd = rsqrtf(var + eps);
   if (tid == 0) {
     stats[2 * blockIdx.x] = mean;
@@ -85,16 +78,18 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_kernel(const float* __
       for (int i = lane; i < HW / 4; i += 64) {
         const float4 v = x4[i];
         float4 o;
-        o.x = silu_f(v.x * ga + be);
-        o.y = silu_f(v.y * ga + be);
-        o.z = silu_f(v.z * ga + be);
-        o.w = silu_f(v.w * ga + be);
+        float u;
+        u = v.x * ga + be; o.x = u * fast_sigmoid(u);
+        u = v.y * ga + be; o.y = u * fast_sigmoid(u);
+        u = v.z * ga + be; o.z = u * fast_sigmoid(u);
+        u = v.w * ga + be; o.w = u * fast_sigmoid(u);
         y4[i] = o;
         ps += (o.x + o.y) + (o.z + o.w);
       }
     } else {
       for (int i = lane; i < HW; i += 64) {
-        const float o = silu_f(xc[i] * ga + be);
+        const float u = xc[i] * ga + be;
+        const float o = u * fast_sigmoid(u);
         yc[i] = o;
         ps += o;
       }
@@ -118,7 +113,11 @@ struct GateBwd {
   const float* dpool;  // [N,C]     gradient wrt the SE squeeze (pooled mean)
 };
 
-template <int MODE>  // 0: upstream gradient given as a tensor; 1: rebuilt from the gate backward maps
+// Backward, one workgroup per (sample, group), one wave per channel.
+//   pass 1: du = upstream * silu'(u) is written to dx (scratch use of the output buffer) while the per-channel and
+//           per-group sums are accumulated;  pass 2: dx = rstd * (du*gamma - s1 - xhat*s2) in place (du comes back
+//           from L2).  MODE 0: upstream gradient given as a tensor; MODE 1: rebuilt from the gate backward maps.
+template <int MODE, int V>   // V = 4: float4 path (HW % 4 == 0), V = 1: scalar
 __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_kernel(const float* __restrict__ x,
                                                                    const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta,
@@ -136,35 +135,53 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_kernel(const float* __
   if (tid < 2) acc[tid] = 0.f;
   __syncthreads();
 
-  // upstream gradient wrt a = silu(u) at (channel c, pixel i); `aval` = silu(u)
-  auto upstream = [&](int c, int i, float aval) -> float {
-    if (MODE == 0) {
-      return dA[(long long)n * st_dA + (long long)c * HW + i];
-    } else {
-      const float sc = gb.s[(long long)n * C + c];
-      const long long np = (long long)n * HW + i;
-      (void)aval;  // the tie test must see the forward's exact product, so use the stored activation
-      const float U = gb.a2[((long long)n * C + c) * HW + i] * sc;
-      const float dm = gb.dmap[((long long)n * 2 + 1) * HW + i];
-      const float da = gb.dmap[((long long)n * 2) * HW + i];
-      const float mx = gb.umax[((long long)n * 2 + 1) * HW + i];
-      float dU = gb.dout[((long long)n * C + c) * HW + i] * gb.gate[np] + da * inv_c;
-      if (U == mx) dU += dm / gb.cnt[np];
-      return dU * sc + gb.dpool[(long long)n * C + c] * inv_hw;
-    }
-  };
+  typedef float vec_t __attribute__((ext_vector_type(V)));
+  const int HWV = HW / V;
 
   for (int cl = wave; cl < cpg; cl += GN_THREADS / 64) {
     const int c = g * cpg + cl;
     const float ga = gamma[c], be = beta[c];
-    const float* xc = x + ((long long)n * C + c) * HW;
+    const long long nc = (long long)n * C + c;
+    const vec_t* xc = reinterpret_cast<const vec_t*>(x + nc * HW);
+    vec_t* dxc = reinterpret_cast<vec_t*>(dx + nc * HW);
+    const vec_t* dAc = MODE == 0 ? reinterpret_cast<const vec_t*>(dA + (long long)n * st_dA + (long long)c * HW) : nullptr;
+    const vec_t* a2c = MODE == 1 ? reinterpret_cast<const vec_t*>(gb.a2 + nc * HW) : nullptr;
+    const vec_t* doc = MODE == 1 ? reinterpret_cast<const vec_t*>(gb.dout + nc * HW) : nullptr;
+    const vec_t* gtc = MODE == 1 ? reinterpret_cast<const vec_t*>(gb.gate + (long long)n * HW) : nullptr;
+    const vec_t* dac = MODE == 1 ? reinterpret_cast<const vec_t*>(gb.dmap + (long long)n * 2 * HW) : nullptr;
+    const vec_t* dmc = MODE == 1 ? reinterpret_cast<const vec_t*>(gb.dmap + ((long long)n * 2 + 1) * HW) : nullptr;
+    const vec_t* mxc = MODE == 1 ? reinterpret_cast<const vec_t*>(gb.umax + ((long long)n * 2 + 1) * HW) : nullptr;
+    const vec_t* ctc = MODE == 1 ? reinterpret_cast<const vec_t*>(gb.cnt + (long long)n * HW) : nullptr;
+    const float sc = MODE == 1 ? gb.s[nc] : 0.f;
+    const float dpl = MODE == 1 ? gb.dpool[nc] * inv_hw : 0.f;
     float sd = 0.f, sdx = 0.f;
-    for (int i = lane; i < HW; i += 64) {
-      const float xh = (xc[i] - mean) * rstd;
-      const float u = xh * ga + be;
-      const float du = upstream(c, i, silu_f(u)) * silu_grad(u);
-      sd += du;
-      sdx += du * xh;
+    for (int i = lane; i < HWV; i += 64) {
+      const vec_t xv = xc[i];
+      vec_t up;
+      if (MODE == 0) {
+        up = dAc[i];
+      } else {
+        const vec_t a2v = a2c[i], dov = doc[i], gtv = gtc[i], dav = dac[i], dmv = dmc[i], mxv = mxc[i], ctv = ctc[i];
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+          const float U = a2v[k] * sc;                  // bit-exact forward product: operand of the tie test
+          float dU = dov[k] * gtv[k] + dav[k] * inv_c;
+          if (U == mxv[k]) dU += dmv[k] / ctv[k];
+          up[k] = dU * sc + dpl;
+        }
+      }
+      vec_t duv;
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        const float xh = (xv[k] - mean) * rstd;
+        const float u = xh * ga + be;
+        const float sg = fast_sigmoid(u);
+        const float du = up[k] * (sg * (1.f + u * (1.f - sg)));
+        duv[k] = du;
+        sd += du;
+        sdx += du * xh;
+      }
+      dxc[i] = duv;
     }
     sd = wave_sum(sd);
     sdx = wave_sum(sdx);
@@ -175,20 +192,25 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_kernel(const float* __
       atomicAdd(&acc[1], sdx * ga);
     }
   }
-  __syncthreads();
+  __syncthreads();   // also orders this wave's du stores before its own re-reads below (same lanes, same addresses)
   const float m = 1.f / (float)(cpg * HW);
   const float s1 = acc[0] * m, s2 = acc[1] * m;
 
   for (int cl = wave; cl < cpg; cl += GN_THREADS / 64) {
     const int c = g * cpg + cl;
-    const float ga = gamma[c], be = beta[c];
-    const float* xc = x + ((long long)n * C + c) * HW;
-    float* dxc = dx + ((long long)n * C + c) * HW;
-    for (int i = lane; i < HW; i += 64) {
-      const float xh = (xc[i] - mean) * rstd;
-      const float u = xh * ga + be;
-      const float du = upstream(c, i, silu_f(u)) * silu_grad(u);
-      dxc[i] = rstd * (du * ga - s1 - xh * s2);
+    const float ga = gamma[c];
+    const long long nc = (long long)n * C + c;
+    const vec_t* xc = reinterpret_cast<const vec_t*>(x + nc * HW);
+    vec_t* dxc = reinterpret_cast<vec_t*>(dx + nc * HW);
+    for (int i = lane; i < HWV; i += 64) {
+      const vec_t xv = xc[i];
+      vec_t dv = dxc[i];
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        const float xh = (xv[k] - mean) * rstd;
+        dv[k] = rstd * (dv[k] * ga - s1 - xh * s2);
+      }
+      dxc[i] = dv;
     }
   }
 }
@@ -216,8 +238,12 @@ int cm_gn_silu_bwd(const float* x, const float* gamma, const float* beta, const 
                    cm_stream stream) {
   if (n <= 0 || c <= 0 || hw <= 0 || groups <= 0 || c % groups) return -22;
   GateBwd gb = {};
-  gn_silu_bwd_kernel<0><<<n * groups, GN_THREADS, 0, (hipStream_t)stream>>>(x, gamma, beta, stats, dA, st_dA, gb, dx,
-                                                                            dgamma, dbeta, c, hw, groups);
+  if ((hw % 4) == 0 && (st_dA % 4) == 0)
+    gn_silu_bwd_kernel<0, 4><<<n * groups, GN_THREADS, 0, (hipStream_t)stream>>>(x, gamma, beta, stats, dA, st_dA, gb,
+                                                                                 dx, dgamma, dbeta, c, hw, groups);
+  else
+    gn_silu_bwd_kernel<0, 1><<<n * groups, GN_THREADS, 0, (hipStream_t)stream>>>(x, gamma, beta, stats, dA, st_dA, gb,
+                                                                                 dx, dgamma, dbeta, c, hw, groups);
   CM_CHECK_LAUNCH();
   return 0;
 }
@@ -229,8 +255,12 @@ int cm_gn_silu_bwd_gated(const float* x, const float* gamma, const float* beta, 
   if (n <= 0 || c <= 0 || hw <= 0 || groups <= 0 || c % groups) return -22;
   GateBwd gb;
   gb.a2 = a2; gb.dout = dout; gb.gate = gate; gb.dmap = dmap; gb.umax = fmap; gb.cnt = cnt; gb.s = s; gb.dpool = dpool;
-  gn_silu_bwd_kernel<1><<<n * groups, GN_THREADS, 0, (hipStream_t)stream>>>(x, gamma, beta, stats, nullptr, 0, gb, dx,
-                                                                            dgamma, dbeta, c, hw, groups);
+  if ((hw % 4) == 0)
+    gn_silu_bwd_kernel<1, 4><<<n * groups, GN_THREADS, 0, (hipStream_t)stream>>>(x, gamma, beta, stats, nullptr, 0, gb,
+                                                                                 dx, dgamma, dbeta, c, hw, groups);
+  else
+    gn_silu_bwd_kernel<1, 1><<<n * groups, GN_THREADS, 0, (hipStream_t)stream>>>(x, gamma, beta, stats, nullptr, 0, gb,
+                                                                                 dx, dgamma, dbeta, c, hw, groups);
   CM_CHECK_LAUNCH();
   return 0;
 }

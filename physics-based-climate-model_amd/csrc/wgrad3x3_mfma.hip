@@ -10,6 +10,7 @@
 // walks the pixels two at a time (one 32x32x2 MFMA k-step).  Partial blocks are accumulated with fp32 atomics into
 // a tap-major staging buffer G[o][tap][c] (32 consecutive channels = one 128-byte segment per half-wave, the access
 // shape MI355X float atomics run at full rate on), which cm_wgrad3x3_unpack then transposes into the parameter layout.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/climate_hip.h"
 
@@ -26,28 +27,33 @@ struct WgArgs {
   int Ctot, c_off;  // channel count / offset of this conv's input range inside the full weight
   int N, H, W, Cout;
   int tiles_x, tiles_y, units, units_per_block;
+  int dbg;  // diagnostic ablation bits (CM_WGRAD_DBG): 1 skip global loads, 2 skip MFMA phase, 4 skip atomics
 };
 
-template <int TH, int TW, int S, int MO, bool DUAL>
-__global__ __launch_bounds__(192) void wgrad3x3_mfma_kernel(WgArgs a) {
-  constexpr int THREADS = 192;
+// Wave roles: wave = (group, kernel row dy); group = (mo, ks): mo selects the 32-cout sub-block, ks the share of the
+// unit's pixel pairs.  Every wave owns 3 accumulators (the three taps of its kernel row).
+template <int TH, int TW, int S, int MO, int KS, bool DUAL>
+__global__ __launch_bounds__(192 * MO * KS, 2) void wgrad3x3_mfma_kernel(WgArgs a) {
+  constexpr int THREADS = 192 * MO * KS;
   constexpr int PITCH = TW + 2;
   constexpr int SS = (TH + 2) * PITCH;
   constexpr int CS0 = S * SS;
   constexpr int CS = (CS0 % 2 == 0) ? CS0 + 1 : CS0;  // odd channel pitch: 32 channels hit 32 banks
   constexpr int PIX = S * TH * TW;
   constexpr int PP = (PIX % 2 == 0) ? PIX + 1 : PIX;  // odd cout pitch
-  constexpr int XN = 32 * CS0;                        // elements staged (pitch CS in LDS)
-  constexpr int DN = 32 * MO * PIX;
-  constexpr int NLX = (XN + THREADS - 1) / THREADS;
-  constexpr int NLD = (DN + THREADS - 1) / THREADS;
-  static_assert((TH * TW) % 2 == 0, "pixel pairs must not straddle samples");
+  constexpr int RSTEP = (TW % 2) ? 2 : 1;               // tile rows per MFMA-loop iteration
+  constexpr int NPAIR = RSTEP * TW / 2;                 // pixel pairs (MFMA k-steps) per iteration
+  constexpr int ITERS_PER_SAMPLE = TH / RSTEP;
+  constexpr int ITERS = S * ITERS_PER_SAMPLE;
+  static_assert(TH % RSTEP == 0, "odd tile widths need an even tile height");
 
   __shared__ float Xl[32 * CS];
   __shared__ float Dl[32 * MO * PP];
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;  // wave == kernel row dy
+  const int lane = tid & 63, wave = tid >> 6;
+  const int dyrow = wave % 3, grp = wave / 3;
+  const int mo = grp % MO, ks = grp / MO;
   const int l31 = lane & 31, half = lane >> 5;
   const int HW = a.H * a.W;
   const int co0 = blockIdx.y * 32 * MO;
@@ -61,98 +67,162 @@ __global__ __launch_bounds__(192) void wgrad3x3_mfma_kernel(WgArgs a) {
   const int C0 = a.C0, N = a.N, H = a.H, W = a.W, Cout = a.Cout;
   const int tiles_x = a.tiles_x, tiles_y = a.tiles_y;
 
-  f32x16 acc[MO][3];
+  f32x16 acc[3];
 #pragma unroll
-  for (int m = 0; m < MO; ++m)
+  for (int d = 0; d < 3; ++d)
 #pragma unroll
-    for (int d = 0; d < 3; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][d][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
 
-  // B operand lane bases: channel l31, kernel row = wave; second k-slice (half) is the next pixel: +1, or +3 when
+  // B operand lane bases: channel l31, kernel row dyrow; second k-slice (half) is the next pixel: +1, or +3 when
   // the pair wraps to the next tile row (only possible for odd TW).
-  const int bN = l31 * CS + wave * PITCH + half;
-  const int bW = l31 * CS + wave * PITCH + half * (PITCH - TW + 1);
-  const int aB = l31 * PP + half;
+  const int bN = l31 * CS + dyrow * PITCH + half;
+  const int bW = l31 * CS + dyrow * PITCH + half * (PITCH - TW + 1);
+  const int aB = (mo * 32 + l31) * PP + half;
 
   const int u_begin = blockIdx.x * a.units_per_block;
   const int u_end = min(a.units, u_begin + a.units_per_block);
 
-  for (int u = u_begin; u < u_end; ++u) {
+  // Register prefetch: the global loads of unit u+1 are in flight while unit u is in its MFMA phase.
+  // Staging is ROW based: a work item is 4 consecutive columns of one (channel, sample, tile-row); its index is
+  // decomposed once per item (not per element) and the 4 elements are loaded through a buffer descriptor whose range
+  // check returns 0 for out-of-image / out-of-batch / out-of-channel lanes (offset 0xFFFFFFFF), so there are no
+  // validity masks and nothing consumes the loaded values before the LDS store of the next iteration.
+  constexpr int XTPR = (PITCH + 3) / 4;                 // items per haloed X row
+  constexpr int XROWS = 32 * S * (TH + 2);
+  constexpr int XITEMS = XROWS * XTPR;
+  constexpr int NIX = (XITEMS + THREADS - 1) / THREADS;
+  constexpr int DTPR = (TW + 3) / 4;                    // items per dY row
+  constexpr int DROWS = 32 * MO * S * TH;
+  constexpr int DITEMS = DROWS * DTPR;
+  constexpr int NID = (DITEMS + THREADS - 1) / THREADS;
+  float xr[NIX][4], dr[NID][4];
+  auto load_unit = [&](int u) {
     int t = u;
     const int tx = t % tiles_x;
     t /= tiles_x;
     const int ty = t % tiles_y;
     const int g = t / tiles_y;
     const int x0 = tx * TW, y0 = ty * TH, n0 = g * S;
-
-    __syncthreads();  // previous unit's MFMA phase has finished reading LDS
-    // ---- stage X: 32 channels x S samples x haloed tile (zero outside image / batch / channel range) ----
-#pragma unroll 4
-    for (int i = 0; i < NLX; ++i) {
-      const int e = tid + i * THREADS;
-      const int c = e / CS0, r1 = e % CS0;
-      const int s = r1 / SS, r2 = r1 % SS;
-      const int row = r2 / PITCH, col = r2 % PITCH;
-      const int gy = y0 - 1 + row, gx = x0 - 1 + col;
+    const float* xb0 = a_x0 + (long long)n0 * sx0;
+    const float* xb1 = DUAL ? a_x1 + (long long)n0 * sx1 : a_x0;
+    const float* db = a_dy + (long long)n0 * sdy + (long long)co0 * HW;
+    // descriptors over [base, base + 2 GiB): every valid element of this unit lies inside, 0xFFFFFFFF lies outside
+    const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb0), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb1), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(db), 0, 0x7FFFFFFF, 0x00020000);
+    int tq = tid;
+    asm volatile("" : "+v"(tq));   // opaque per call: keeps the per-item index math out of loop-invariant registers
+#pragma unroll
+    for (int it = 0; it < NIX; ++it) {
+      const int item = tq + it * THREADS;
+      const int row = item / XTPR, col0 = (item % XTPR) * 4;
+      const int c = row / (S * (TH + 2)), rem = row % (S * (TH + 2));
+      const int s = rem / (TH + 2), r = rem % (TH + 2);
+      const int gy = y0 - 1 + r, gx0 = x0 - 1 + col0;
       const int ch = ci0 + c;
-      const bool ok = (e < XN) && ch < Cin && (n0 + s < N) && gy >= 0 && gy < H && gx >= 0 && gx < W;
-      float v = 0.f;
-      if (ok) {
-        if (!DUAL || ch < C0)
-          v = a_x0[(long long)(n0 + s) * sx0 + (long long)ch * HW + gy * W + gx];
-        else
-          v = a_x1[(long long)(n0 + s) * sx1 + (long long)(ch - C0) * HW + gy * W + gx];
+      const bool rowok = (item < XITEMS) && ch < Cin && (n0 + s < N) && gy >= 0 && gy < H;
+      // virtual concat: channels [0, C0) come from x0, [C0, Cin) from x1; the other source's lane is out of range (-> 0)
+      const bool in1 = DUAL && ch >= C0;
+      const int off0 = (s * (int)sx0 + ch * HW + gy * W + gx0) * 4;
+      const int off1 = (s * (int)sx1 + (ch - C0) * HW + gy * W + gx0) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool ok = rowok && (col0 + j < PITCH) && (gx0 + j >= 0) && (gx0 + j < W);
+        int v = __builtin_amdgcn_raw_buffer_load_b32(rx0, (ok && !in1) ? off0 + 4 * j : -1, 0, 0);
+        if (DUAL) v |= __builtin_amdgcn_raw_buffer_load_b32(rx1, (ok && in1) ? off1 + 4 * j : -1, 0, 0);
+        xr[it][j] = __int_as_float(v);
       }
-      if (e < XN) Xl[c * CS + r1] = v;
     }
-    // ---- stage dY: 32*MO couts x PIX pixels (zero outside the image / batch) ----
-#pragma unroll 4
-    for (int i = 0; i < NLD; ++i) {
-      const int e = tid + i * THREADS;
-      const int o = e / PIX, q = e % PIX;
-      const int s = q / (TH * TW), rem = q % (TH * TW);
-      const int py = rem / TW, px = rem % TW;
-      const int gy = y0 + py, gx = x0 + px, co = co0 + o;
-      const bool ok = (e < DN) && co < Cout && (n0 + s < N) && gy < H && gx < W;
-      const float v = ok ? a_dy[(long long)(n0 + s) * sdy + (long long)co * HW + gy * W + gx] : 0.f;
-      if (e < DN) Dl[o * PP + q] = v;
+#pragma unroll
+    for (int it = 0; it < NID; ++it) {
+      const int item = tq + it * THREADS;
+      const int row = item / DTPR, col0 = (item % DTPR) * 4;
+      const int o = row / (S * TH), rem = row % (S * TH);
+      const int s = rem / TH, r = rem % TH;
+      const int gy = y0 + r, gx0 = x0 + col0;
+      const bool rowok = (item < DITEMS) && co0 + o < Cout && (n0 + s < N) && gy < H;
+      const int off = (s * (int)sdy + o * HW + gy * W + gx0) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool ok = rowok && (col0 + j < TW) && (gx0 + j < W);
+        dr[it][j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, ok ? off + 4 * j : -1, 0, 0));
+      }
+    }
+  };
+
+  const int dbg = a.dbg;
+  if (u_begin < u_end && !(dbg & 1)) load_unit(u_begin);
+  for (int u = u_begin; u < u_end; ++u) {
+    __syncthreads();  // previous unit's MFMA phase has finished reading LDS
+    int ts = tid;
+    asm volatile("" : "+v"(ts));
+#pragma unroll
+    for (int it = 0; it < NIX; ++it) {
+      const int item = ts + it * THREADS;
+      const int row = item / XTPR, col0 = (item % XTPR) * 4;
+      const int c = row / (S * (TH + 2)), rem = row % (S * (TH + 2));
+      const int base = c * CS + rem * PITCH + col0;
+      if (item < XITEMS) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (col0 + j < PITCH) Xl[base + j] = xr[it][j];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NID; ++it) {
+      const int item = ts + it * THREADS;
+      const int row = item / DTPR, col0 = (item % DTPR) * 4;
+      const int o = row / (S * TH), rem = row % (S * TH);
+      const int base = o * PP + rem * TW + col0;
+      if (item < DITEMS) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (col0 + j < TW) Dl[base + j] = dr[it][j];
+      }
     }
     __syncthreads();
+    if (u + 1 < u_end && !(dbg & 1)) load_unit(u + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (dbg & 2) continue;
 
+    // MFMA phase: a runtime loop over row groups (RSTEP tile rows each; 2 for odd TW so that pixel pairs tile the
+    // group exactly), the pairs inside a group unrolled with compile-time LDS offsets.  The KS wave groups take
+    // alternate row groups.
+#pragma unroll 1
+    for (int it = ks; it < ITERS; it += KS) {
+      const int sidx = it / ITERS_PER_SAMPLE, r = (it % ITERS_PER_SAMPLE) * RSTEP;
+      const int xo = sidx * SS + r * PITCH;
+      const int dofs = sidx * (TH * TW) + r * TW;
+      const float* dlp = Dl + aB + dofs;
+      const float* xn = Xl + bN + xo;
+      const float* xw = Xl + bW + xo;
 #pragma unroll
-    for (int kp = 0; kp < PIX / 2; ++kp) {
-      constexpr int TT = TH * TW;
-      const int q0 = 2 * kp;
-      const int f = (q0 / TT) * SS + ((q0 % TT) / TW) * PITCH + (q0 % TW);  // compile-time after unrolling
-      const bool wrap = (q0 % TW) == TW - 1;
-      const int bb = (wrap ? bW : bN) + f;
-      float av[MO], bv[3];
+      for (int j = 0; j < NPAIR; ++j) {
+        const int q0 = 2 * j;
+        const int f = (q0 / TW) * PITCH + (q0 % TW);
+        const bool wrap = (q0 % TW) == TW - 1;
+        const float av = dlp[q0];
+        float bv[3];
 #pragma unroll
-      for (int m = 0; m < MO; ++m) av[m] = Dl[aB + m * 32 * PP + q0];
+        for (int d = 0; d < 3; ++d) bv[d] = wrap ? xw[f + d] : xn[f + d];
 #pragma unroll
-      for (int d = 0; d < 3; ++d) bv[d] = Xl[bb + d];
-#pragma unroll
-      for (int m = 0; m < MO; ++m)
-#pragma unroll
-        for (int d = 0; d < 3; ++d) acc[m][d] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[d], acc[m][d], 0, 0, 0);
+        for (int d = 0; d < 3; ++d) acc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[d], acc[d], 0, 0, 0);
+      }
     }
   }
 
   // ---- accumulate: D[i = cout][j = channel]; lane holds channel ci0 + l31 ----
   const int ch = ci0 + l31;
-  if (ch < Cin && u_begin < u_end) {
+  if (ch < Cin && u_begin < u_end && !(dbg & 4)) {
 #pragma unroll
-    for (int m = 0; m < MO; ++m)
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + mo * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co < Cout) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (co < Cout) {
-#pragma unroll
-          for (int d = 0; d < 3; ++d)
-            unsafeAtomicAdd(a.g + ((long long)co * 9 + wave * 3 + d) * a.Ctot + a.c_off + ch, acc[m][d][r]);
-        }
+        for (int d = 0; d < 3; ++d)
+          unsafeAtomicAdd(a.g + ((long long)co * 9 + dyrow * 3 + d) * a.Ctot + a.c_off + ch, acc[d][r]);
       }
+    }
   }
 }
 
@@ -171,16 +241,21 @@ __global__ void wgrad_unpack_kernel(const float* __restrict__ g, float* __restri
 }
 
 struct WgCfg {
-  int th, tw, s, mo;
+  int th, tw, s, mo, ks;
 };
 constexpr WgCfg kWg[] = {
-    {8, 24, 1, 1},   // 0: 192 px
-    {8, 12, 1, 2},   // 1:  96 px, 64 couts
-    {4, 18, 1, 2},   // 2:  72 px, 64 couts
-    {6, 18, 1, 2},   // 3: 108 px, 64 couts
-    {6, 9, 2, 2},    // 4: 2 samples x 54 px, 64 couts
-    {8, 16, 1, 1},   // 5: generic 128 px
-    {4, 36, 1, 1},   // 6: 144 px
+    {8, 24, 1, 1, 2},   // 0: 192 px, 32 couts, pixel pairs split over 2 wave groups
+    {8, 12, 1, 2, 1},   // 1:  96 px, 64 couts
+    {4, 18, 1, 2, 1},   // 2:  72 px, 64 couts
+    {6, 18, 1, 2, 1},   // 3: 108 px, 64 couts
+    {6, 9, 2, 2, 1},    // 4: 2 samples x 54 px, 64 couts
+    {8, 16, 1, 1, 2},   // 5: generic 128 px, 32 couts
+    {4, 36, 1, 1, 2},   // 6: 144 px, 32 couts
+    {8, 16, 1, 2, 1},   // 7: generic 128 px, 64 couts
+    {6, 9, 4, 2, 2},    // 8: 4 samples x 54 px, 64 couts, 12 waves
+    {12, 18, 1, 2, 2},  // 9: 216 px, 64 couts, 12 waves
+    {8, 24, 1, 1, 1},   // 10: 192 px, 32 couts, 3 waves
+    {8, 16, 1, 1, 1},   // 11: 128 px, 32 couts, 3 waves
 };
 constexpr int kNumWg = sizeof(kWg) / sizeof(kWg[0]);
 
@@ -192,14 +267,25 @@ int launch_wg(const WgArgs& a0, hipStream_t st) {
   a.tiles_y = cdiv(a.H, c.th);
   a.units = a.tiles_x * a.tiles_y * cdiv(a.N, c.s);
   const int gy = cdiv(a.Cout, 32 * c.mo), gz = cdiv(a.C0 + a.C1, 32);
-  // aim for ~4 resident-block rounds worth of workgroups, but keep at least 4 units per block to amortise atomics
-  int p = cdiv(2048, gy * gz);
+  // Size the grid to the number of resident workgroup slots (256 CUs x occupancy): with `rounds4`/4 rounds of
+  // equally loaded workgroups there is no partially filled last round.  a0.units_per_block carries rounds4 (0 = 4).
+  static int occ = 0;
+  if (occ == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, wgrad3x3_mfma_kernel<c.th, c.tw, c.s, c.mo, c.ks, DUAL>,
+                                                     192 * c.mo * c.ks, 0) != hipSuccess || nb < 1)
+      nb = 1;
+    occ = nb;
+  }
+  const int rounds4 = a0.units_per_block > 0 ? a0.units_per_block : 4;
+  long long target = (long long)256 * occ * rounds4 / 4;        // workgroups wanted in total
+  int p = (int)(target / (gy * gz));                            // pixel splits per output tile
   if (p < 1) p = 1;
   int upb = cdiv(a.units, p);
-  if (upb < 4) upb = a.units < 4 ? a.units : 4;
+  if (upb < 1) upb = 1;
   a.units_per_block = upb;
   dim3 grid(cdiv(a.units, upb), gy, gz);
-  wgrad3x3_mfma_kernel<c.th, c.tw, c.s, c.mo, DUAL><<<grid, 192, 0, st>>>(a);
+  wgrad3x3_mfma_kernel<c.th, c.tw, c.s, c.mo, c.ks, DUAL><<<grid, 192 * c.mo * c.ks, 0, st>>>(a);
   CM_CHECK_LAUNCH();
   return 0;
 }
@@ -214,6 +300,11 @@ int dispatch_wg(int cfg, const WgArgs& a, hipStream_t st) {
     case 4: return launch_wg<4, DUAL>(a, st);
     case 5: return launch_wg<5, DUAL>(a, st);
     case 6: return launch_wg<6, DUAL>(a, st);
+    case 7: return launch_wg<7, DUAL>(a, st);
+    case 8: return launch_wg<8, DUAL>(a, st);
+    case 9: return launch_wg<9, DUAL>(a, st);
+    case 10: return launch_wg<10, DUAL>(a, st);
+    case 11: return launch_wg<11, DUAL>(a, st);
     default: return -22;
   }
 }
@@ -252,8 +343,14 @@ int cm_wgrad3x3(const float* x0, long long sx0, int c0, const float* x1, long lo
   a.x0 = x0; a.x1 = x1; a.sx0 = sx0; a.sx1 = sx1; a.C0 = c0; a.C1 = c1;
   a.dy = dy; a.sdy = sdy; a.g = g; a.Ctot = ctot; a.c_off = c_off;
   a.N = n; a.H = h; a.W = w; a.Cout = cout;
-  a.tiles_x = a.tiles_y = a.units = a.units_per_block = 0;
+  a.tiles_x = a.tiles_y = a.units = 0;
+  a.units_per_block = 0;
+  static const int s_dbg = getenv("CM_WGRAD_DBG") ? atoi(getenv("CM_WGRAD_DBG")) : 0;
+  a.dbg = s_dbg;
+
   if (config < 0) config = cm_wgrad3x3_pick_config(n, h, w, cout);
+  if ((config >> 8) > 0) a.units_per_block = config >> 8;   // bits 8.. = grid size in quarter rounds of resident slots
+  config &= 0xff;
   return c1 > 0 ? dispatch_wg<true>(config, a, (hipStream_t)stream) : dispatch_wg<false>(config, a, (hipStream_t)stream);
 }
 

@@ -30,14 +30,14 @@ AUTOTUNE = True
 _TUNED = {}
 
 
-def _pick(key, n_cfg, launch, fallback):
+def _pick(key, candidates, launch, fallback):
     """launch(cfg) enqueues one launch with that configuration into scratch memory."""
     if key in _TUNED:
         return _TUNED[key]
     if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
         return fallback
     best, best_t = fallback, float("inf")
-    for cfg in range(n_cfg):
+    for cfg in (range(candidates) if isinstance(candidates, int) else candidates):
         launch(cfg)
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
@@ -108,7 +108,8 @@ def wgrad3x3(x0, dy, g, c_off=0, x1=None, config=-1):
                 _scratch[0] = torch.empty_like(g)
             check(lib.cm_wgrad3x3(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(dy), dy.stride(0), _p(_scratch[0]),
                                   ctot, c_off, n, h, w, cout, cfg, _stream()), "wgrad3x3 tune")
-        config = _pick(("wgrad3x3", n, h, w, c0, c1, cout), lib.cm_wgrad3x3_num_configs(), launch, -1)
+        cands = [c + (u << 8) for c in range(lib.cm_wgrad3x3_num_configs()) for u in (2, 3, 4, 6, 8)]
+        config = _pick(("wgrad3x3", n, h, w, c0, c1, cout), cands, launch, -1)
     check(lib.cm_wgrad3x3(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(dy),
                           dy.stride(0), _p(g), ctot, c_off, n, h, w, cout, config, _stream()), "wgrad3x3")
     return g

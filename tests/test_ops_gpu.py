@@ -128,7 +128,7 @@ def test_wgrad3x3_all_configs(ops, case):
     wt = torch.zeros(cout, c0 + c1, 3, 3, dtype=torch.float64, requires_grad=True)
     F.conv2d(xin.double(), wt, padding=1).backward(dy.double())
     ctot = c0 + c1 + 4
-    for cfg in list(range(7)) + [-1]:
+    for cfg in list(range(12)) + [-1]:
         g = torch.zeros(cout, 9, ctot, device="cuda")
         ops.wgrad3x3(dev(x0), dev(dy), g, c_off=4, x1=None if x1 is None else dev(x1), config=cfg)
         dw = ops.wgrad3x3_unpack(g)

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Per-layer microbenchmark of the MFMA conv3x3 / wgrad3x3 launchers at BASELINE config-2 shapes (all tile configs).
+
+    python tools/conv_microbench.py [--base 32] [--B 32] [--T 6] [--what conv|wgrad|both]
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from climate_amd import ops  # noqa: E402
+from climate_amd._lib import check, lib  # noqa: E402
+
+
+def layers(b, B, T, H=48, W=72):
+    N = B * T
+    L = [("enc1.c1", N, 5, 0, b, H, W), ("enc1.c2", N, b, 0, b, H, W),
+         ("enc2.c1", N, b, 0, 2 * b, H // 2, W // 2), ("enc2.c2", N, 2 * b, 0, 2 * b, H // 2, W // 2),
+         ("enc3.c1", N, 2 * b, 0, 4 * b, H // 4, W // 4), ("enc3.c2", N, 4 * b, 0, 4 * b, H // 4, W // 4),
+         ("enc4.c1", N, 4 * b, 0, 8 * b, H // 8, W // 8), ("enc4.c2", N, 8 * b, 0, 8 * b, H // 8, W // 8),
+         ("lstm.x", N, 8 * b, 0, 16 * b, H // 8, W // 8), ("lstm.h", B, 4 * b, 0, 16 * b, H // 8, W // 8),
+         ("up3.c1", B, 4 * b, 4 * b, 4 * b, H // 4, W // 4), ("up3.c2", B, 4 * b, 0, 4 * b, H // 4, W // 4),
+         ("up2.c1", B, 2 * b, 2 * b, 2 * b, H // 2, W // 2), ("up2.c2", B, 2 * b, 0, 2 * b, H // 2, W // 2),
+         ("up1.c1", B, b, b, b, H, W), ("up1.c2", B, b, 0, b, H, W)]
+    return L
+
+
+def timeit(fn, reps=5):
+    fn()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3   # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--base", type=int, default=32)
+    ap.add_argument("--B", type=int, default=32)
+    ap.add_argument("--T", type=int, default=6)
+    ap.add_argument("--what", default="both")
+    args = ap.parse_args()
+    st = torch.cuda.current_stream().cuda_stream
+    tot = {"conv": 0.0, "dgrad": 0.0, "wgrad": 0.0}
+    for name, n, c0, c1, co, h, w in layers(args.base, args.B, args.T):
+        ci = c0 + c1
+        x0 = torch.randn(n, c0, h, w, device="cuda")
+        x1 = torch.randn(n, c1, h, w, device="cuda") if c1 else None
+        dy = torch.randn(n, co, h, w, device="cuda")
+        wt = torch.randn(co, ci, 3, 3, device="cuda") * 0.05
+        flops = 2.0 * n * h * w * co * ci * 9
+        if args.what in ("conv", "both"):
+            wp = ops.pack_conv3x3(wt)
+            out = torch.empty(n, co, h, w, device="cuda")
+            res = []
+            for cfg in range(lib.cm_conv3x3_num_configs()):
+                t = timeit(lambda: ops.conv3x3(x0, wp, co, x1=x1, out=out, config=cfg))
+                res.append((t, cfg))
+            res.sort()
+            tot["conv"] += res[0][0]
+            print(f"conv  {name:8s} N={n:3d} {ci:3d}->{co:3d} @{h}x{w}: best cfg {res[0][1]:2d} {res[0][0]:7.1f} us "
+                  f"{flops / res[0][0] / 1e6:6.1f} TF | " + " ".join(f"{c}:{t:.0f}" for t, c in res[1:6]))
+            if name != "enc1.c1":
+                wpd = ops.pack_conv3x3(wt, dgrad=True)
+                outd = torch.empty(n, ci, h, w, device="cuda")
+                res = []
+                for cfg in range(lib.cm_conv3x3_num_configs()):
+                    t = timeit(lambda: ops.conv3x3(dy, wpd, ci, out=outd, config=cfg))
+                    res.append((t, cfg))
+                res.sort()
+                tot["dgrad"] += res[0][0]
+                print(f"dgrad {name:8s} N={n:3d} {co:3d}->{ci:3d} @{h}x{w}: best cfg {res[0][1]:2d} {res[0][0]:7.1f} us "
+                      f"{flops / res[0][0] / 1e6:6.1f} TF | " + " ".join(f"{c}:{t:.0f}" for t, c in res[1:6]))
+        if args.what in ("wgrad", "both"):
+            g = torch.zeros(co, 9, ci, device="cuda")
+            res = []
+            for cfg in range(lib.cm_wgrad3x3_num_configs()):
+                for upb in (2, 3, 4, 6, 8):
+                    t = timeit(lambda: ops.wgrad3x3(x0, dy, g, x1=x1, config=cfg + (upb << 8)))
+                    res.append((t, f"{cfg}/{upb}"))
+            res.sort()
+            tot["wgrad"] += res[0][0]
+            print(f"wgrad {name:8s} N={n:3d} {ci:3d}->{co:3d} @{h}x{w}: best cfg {res[0][1]:>5s} {res[0][0]:7.1f} us "
+                  f"{flops / res[0][0] / 1e6:6.1f} TF | " + " ".join(f"{c}:{t:.0f}" for t, c in res[1:5]))
+    print("sum of best (us):", {k: round(v, 1) for k, v in tot.items()}, "(lstm.h counted once; it runs T-1 times)")
+
+
+if __name__ == "__main__":
+    main()
