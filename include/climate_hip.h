@@ -37,7 +37,9 @@ int cm_pack_conv3x3(const float* w, int cout, int cin_total, int c_off, int cin,
                     cm_stream stream);
 /* out[n, :cout] = conv3x3(cat(in0[:, :c0], in1[:, :c1]), wp) (+ bias) (+ resid).  in1 may be NULL (c1 = 0).
  * resid (nullable) uses the addressing of out (st_resid must equal st_out; resid may alias out).
- * config < 0 picks a tile configuration automatically. */
+ * config < 0 picks a tile configuration automatically; else bits 0-7 = tile configuration, bits 8.. = split of
+ * the input-channel reduction over workgroups (0/1 = none; > 1 accumulates with atomics into a zeroed output and
+ * is not allowed with an in-place residual). */
 int cm_conv3x3(const float* in0, long long st0, int c0, const float* in1, long long st1, int c1, const float* wp,
                const float* bias, const float* resid, long long st_resid, float* out, long long st_out, int n, int h,
                int w, int cout, int config, cm_stream stream);

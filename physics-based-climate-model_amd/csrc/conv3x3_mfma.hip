@@ -33,6 +33,7 @@ struct Conv3Args {
   float* out;
   long long sto;
   int N, H, W, Cout, CoutP, nchunks, tiles_x, tiles_y;
+  int ksplit;  // > 1: blockIdx.z owns a share of the K-chunks and accumulates into a pre-zeroed output with atomics
 };
 
 template <int TH, int TW, int S, int WAVES, int NPT, int WM, int KC, bool DUAL>
@@ -166,11 +167,15 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_mfma_kernel(Conv3Args a) {
 
   const int wl_lane = half * BCO + l31;
 
-  load_chunk(0);
-  for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+  const int cps = (a.nchunks + a.ksplit - 1) / a.ksplit;
+  const int chunk_begin = blockIdx.z * cps;
+  const int chunk_end = min(a.nchunks, chunk_begin + cps);
+  if (chunk_begin >= chunk_end) return;   // uniform for the whole workgroup
+  load_chunk(chunk_begin);
+  for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
     store_chunk();
     __syncthreads();
-    if (chunk + 1 < a.nchunks) load_chunk(chunk + 1);
+    if (chunk + 1 < chunk_end) load_chunk(chunk + 1);
 #pragma unroll
     for (int cp = 0; cp < KC / 2; ++cp) {
 #pragma unroll
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_mfma_kernel(Conv3Args a) {
   // Bias and residual are folded into the accumulators in their own (wave-uniform) blocks first, so that their loads
   // are issued back to back and the store loop below contains no load: on CDNA4 vmcnt also counts stores, and a
   // load->use inside the store loop would make every store wait for the previous one.
-  if (a.bias) {
+  if (a.bias && blockIdx.z == 0) {
 #pragma unroll
     for (int m = 0; m < WM; ++m) {
       float bv[16];
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_mfma_kernel(Conv3Args a) {
         for (int r = 0; r < 16; ++r) acc[m][p][r] += bv[r];
     }
   }
-  if (a.resid) {
+  if (a.resid && blockIdx.z == 0) {
 #pragma unroll
     for (int m = 0; m < WM; ++m)
 #pragma unroll
@@ -233,7 +238,12 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_mfma_kernel(Conv3Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (co < a.Cout) a.out[obase[p] + (long long)co * HW] = acc[m][p][r];
+          if (co < a.Cout) {
+            if (a.ksplit > 1)
+              unsafeAtomicAdd(a.out + obase[p] + (long long)co * HW, acc[m][p][r]);
+            else
+              a.out[obase[p] + (long long)co * HW] = acc[m][p][r];
+          }
         }
       }
     }
@@ -260,6 +270,12 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restri
     }
     wp[i] = v;
   }
+}
+
+__global__ void zero_out_kernel(float* __restrict__ out, long long sto, int n, long long per) {
+  const long long total = (long long)n * per;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+    out[(i / per) * sto + (i % per)] = 0.f;
 }
 
 struct TileCfg {
@@ -289,7 +305,14 @@ int launch_cfg(const Conv3Args& a0, hipStream_t st) {
   Conv3Args a = a0;
   a.tiles_x = cdiv(a.W, c.tw);
   a.tiles_y = cdiv(a.H, c.th);
-  dim3 grid(a.tiles_x * a.tiles_y * cdiv(a.N, c.s), cdiv(a.Cout, 32 * c.wm));
+  if (a.ksplit > a.nchunks) a.ksplit = a.nchunks;
+  if (a.ksplit < 1) a.ksplit = 1;
+  if (a.ksplit > 1) {
+    const long long per = (long long)a.Cout * a.H * a.W;
+    long long zb = ((long long)a.N * per + 255) / 256;
+    zero_out_kernel<<<(int)(zb > 2048 ? 2048 : zb), 256, 0, st>>>(a.out, a.sto, a.N, per);
+  }
+  dim3 grid(a.tiles_x * a.tiles_y * cdiv(a.N, c.s), cdiv(a.Cout, 32 * c.wm), a.ksplit);
   conv3x3_mfma_kernel<c.th, c.tw, c.s, c.waves, c.npt, c.wm, KCH, DUAL><<<grid, c.waves * 64, 0, st>>>(a);
   CM_CHECK_LAUNCH();
   return 0;
@@ -379,6 +402,9 @@ int cm_conv3x3(const float* in0, long long st0, int c0, const float* in1, long l
   a.nchunks = (c0 + c1 + KCH - 1) / KCH;
   a.tiles_x = a.tiles_y = 0;
   if (config < 0) config = cm_conv3x3_pick_config(n, h, w, cout);
+  a.ksplit = config >> 8;                    // bits 8.. = K split over blockIdx.z (0/1 = none)
+  config &= 0xff;
+  if (a.ksplit > 1 && resid == out) return -22;   // the in-place residual would be zeroed
   return c1 > 0 ? dispatch<true>(config, a, (hipStream_t)stream) : dispatch<false>(config, a, (hipStream_t)stream);
 }
 

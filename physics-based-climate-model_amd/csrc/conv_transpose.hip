@@ -10,17 +10,21 @@
 
 namespace {
 
-constexpr int OT = 8;   // output channels per thread (fwd) / input channels per thread (bwd data)
+constexpr int OT = 8;    // output channels per thread (fwd) / input channels per thread (bwd data)
+constexpr int KCH = 64;  // reduction-channel chunk whose weight slab is staged in LDS
 
-// thread <-> input pixel; blockIdx.y = sample; blockIdx.z = chunk of OT output channels
+// thread <-> input pixel; blockIdx.y = sample; blockIdx.z = chunk of OT output channels.
+// The weight slab w[c][o0..o0+OT)[4] of a KCH-channel chunk is staged in LDS (broadcast reads); activations stream
+// coalesced along pixels with the channel loop unrolled so several loads are in flight.
 __global__ __launch_bounds__(256) void convT_fwd_kernel(const float* __restrict__ x, long long sx,
                                                          const float* __restrict__ w, const float* __restrict__ b,
                                                          float* __restrict__ y, long long sy, int Ci, int Co, int H,
                                                          int W) {
+  __shared__ __attribute__((aligned(16))) float wsh[KCH][OT * 4];
   const int HW = H * W, Wo = 2 * W;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = blockIdx.y, o0 = blockIdx.z * OT;
-  if (p >= HW) return;
+  const bool live = p < HW;
   float acc[OT][4];
 #pragma unroll
   for (int j = 0; j < OT; ++j) {
@@ -28,18 +32,30 @@ __global__ __launch_bounds__(256) void convT_fwd_kernel(const float* __restrict_
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[j][k] = bv;
   }
-  const float* xp = x + (long long)n * sx + p;
-  for (int c = 0; c < Ci; ++c) {
-    const float xv = xp[(long long)c * HW];
-    const float* wc = w + ((long long)c * Co + o0) * 4;
+  const float* xp = x + (long long)n * sx + (live ? p : 0);
+  for (int c0 = 0; c0 < Ci; c0 += KCH) {
+    const int kc = min(KCH, Ci - c0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < kc * OT * 4; i += blockDim.x) {
+      const int c = i / (OT * 4), r = i % (OT * 4);
+      wsh[c][r] = (o0 + r / 4 < Co) ? w[((long long)(c0 + c) * Co + o0) * 4 + r] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int c = 0; c < kc; ++c) {
+      const float xv = xp[(long long)(c0 + c) * HW];
+      const float4* wr = reinterpret_cast<const float4*>(&wsh[c][0]);
 #pragma unroll
-    for (int j = 0; j < OT; ++j) {
-      if (o0 + j < Co) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc[j][k] += xv * wc[j * 4 + k];
+      for (int j = 0; j < OT; ++j) {
+        const float4 wv = wr[j];
+        acc[j][0] += xv * wv.x;
+        acc[j][1] += xv * wv.y;
+        acc[j][2] += xv * wv.z;
+        acc[j][3] += xv * wv.w;
       }
     }
   }
+  if (!live) return;
   const int yy = p / W, xx = p % W;
 #pragma unroll
   for (int j = 0; j < OT; ++j) {
@@ -51,30 +67,43 @@ __global__ __launch_bounds__(256) void convT_fwd_kernel(const float* __restrict_
   }
 }
 
-// dx[n,c,y,x] = sum_{o,k} dy[n,o,2y+ky,2x+kx] * W[c,o,k];  thread <-> input pixel, OT input channels per thread
+// dx[n,c,y,x] = sum_{o,k} dy[n,o,2y+ky,2x+kx] * W[c,o,k];  thread <-> input pixel, OT input channels per thread;
+// weight slab w[c0..c0+OT)[o chunk][4] staged in LDS as [o][OT][4].
 __global__ __launch_bounds__(256) void convT_bwd_data_kernel(const float* __restrict__ dy, long long sdy,
                                                               const float* __restrict__ w, float* __restrict__ dx,
                                                               long long sdx, int Ci, int Co, int H, int W) {
+  __shared__ __attribute__((aligned(16))) float wsh[KCH][OT * 4];
   const int HW = H * W, Wo = 2 * W;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = blockIdx.y, c0 = blockIdx.z * OT;
-  if (p >= HW) return;
-  const int yy = p / W, xx = p % W;
+  const bool live = p < HW;
+  const int pp = live ? p : 0;
+  const int yy = pp / W, xx = pp % W;
   float acc[OT];
 #pragma unroll
   for (int j = 0; j < OT; ++j) acc[j] = 0.f;
   const float* dp = dy + (long long)n * sdy + (long long)(2 * yy) * Wo + 2 * xx;
-  for (int o = 0; o < Co; ++o) {
-    const float2 d0 = *reinterpret_cast<const float2*>(dp + (long long)o * 4 * HW);
-    const float2 d1 = *reinterpret_cast<const float2*>(dp + (long long)o * 4 * HW + Wo);
+  for (int o0 = 0; o0 < Co; o0 += KCH) {
+    const int ko = min(KCH, Co - o0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < ko * OT * 4; i += blockDim.x) {
+      const int o = i / (OT * 4), r = i % (OT * 4), j = r / 4, k = r % 4;
+      wsh[o][r] = (c0 + j < Ci) ? w[((long long)(c0 + j) * Co + o0 + o) * 4 + k] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int o = 0; o < ko; ++o) {
+      const float2 d0 = *reinterpret_cast<const float2*>(dp + (long long)(o0 + o) * 4 * HW);
+      const float2 d1 = *reinterpret_cast<const float2*>(dp + (long long)(o0 + o) * 4 * HW + Wo);
+      const float4* wr = reinterpret_cast<const float4*>(&wsh[o][0]);
 #pragma unroll
-    for (int j = 0; j < OT; ++j) {
-      if (c0 + j < Ci) {
-        const float* wc = w + ((long long)(c0 + j) * Co + o) * 4;
-        acc[j] += d0.x * wc[0] + d0.y * wc[1] + d1.x * wc[2] + d1.y * wc[3];
+      for (int j = 0; j < OT; ++j) {
+        const float4 wv = wr[j];
+        acc[j] += d0.x * wv.x + d0.y * wv.y + d1.x * wv.z + d1.y * wv.w;
       }
     }
   }
+  if (!live) return;
 #pragma unroll
   for (int j = 0; j < OT; ++j)
     if (c0 + j < Ci) dx[(long long)n * sdx + (long long)(c0 + j) * HW + p] = acc[j];

@@ -89,7 +89,10 @@ def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1):
                 _scratch[0] = torch.empty(n, cout, h, w, device=x0.device, dtype=torch.float32)
             check(lib.cm_conv3x3(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(wp), _p(bias), None, 0,
                                  _p(_scratch[0]), _scratch[0].stride(0), n, h, w, cout, cfg, _stream()), "conv3x3 tune")
-        config = _pick(("conv3x3", n, h, w, c0, c1, cout), lib.cm_conv3x3_num_configs(), launch, -1)
+        nchunks = (c0 + c1 + 7) // 8
+        splits = [1] + [k for k in (2, 4, 8) if nchunks >= 4 * k and not (resid is not None and resid.data_ptr() == out.data_ptr())]
+        cands = [c + ((k if k > 1 else 0) << 8) for c in range(lib.cm_conv3x3_num_configs()) for k in splits]
+        config = _pick(("conv3x3", n, h, w, c0, c1, cout, len(splits)), cands, launch, -1)
     check(lib.cm_conv3x3(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(wp), _p(bias),
                          _p(resid), 0 if resid is None else resid.stride(0), _p(out), out.stride(0), n, h, w, cout,
                          config, _stream()), "conv3x3")

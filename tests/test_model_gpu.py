@@ -133,8 +133,9 @@ def test_cfg2_full_size_checksums(amd):
 
 
 def test_properties_full_size(amd):
-    """Size-independent properties at config-2 size: per-sample independence (a sub-batch gives bit-identical
-    rows), eval/no_grad forward equals the training forward, frames beyond the batch fold are independent."""
+    """Size-independent properties at config-2 size: per-sample independence (a sub-batch / a permuted batch gives
+    the same rows; only the split-K convolutions' atomic summation order may differ, hence 1e-6 instead of bit
+    equality), eval/no_grad forward equals the training forward, strided input is accepted."""
     in_ch, out_ch, base, T, B, H, W = 5, 2, 32, 6, 32, 48, 72
     m = _make(amd, in_ch, out_ch, base, T)
     gen = torch.Generator("cpu").manual_seed(5)
@@ -145,16 +146,16 @@ def test_properties_full_size(amd):
         m.eval()
         ev = m(x[:16])
     assert torch.isfinite(full).all()
-    assert torch.equal(full[:16], half) and torch.equal(half, ev)
+    assert rel_l2(half, full[:16]) < 1e-6 and rel_l2(ev, half) < 1e-6
     perm = torch.randperm(B, generator=gen)
     with torch.no_grad():
         pp = m(x[perm.cuda()])
-    assert torch.equal(pp, full[perm.cuda()])
+    assert rel_l2(pp, full[perm.cuda()]) < 1e-6
     # non-contiguous input (a strided view) is accepted, like nn.Conv2d accepts it
     xt = x[:4].transpose(0, 1).contiguous().transpose(0, 1)
     assert not xt.is_contiguous()
     with torch.no_grad():
-        assert torch.equal(m(xt), full[:4])
+        assert rel_l2(m(xt), full[:4]) < 1e-6
 
 
 def test_error_behaviour(amd):
@@ -176,4 +177,4 @@ def test_checkpoint_roundtrip(amd):
     m2 = m2.cuda()
     x = torch.randn(2, 3, 5, 16, 24, device="cuda")
     with torch.no_grad():
-        assert torch.equal(m(x), m2(x))
+        assert rel_l2(m(x), m2(x)) < 1e-6

@@ -350,6 +350,23 @@ def test_autotune_is_cached_and_correct(ops):
     x = rnd(4, 16, 12, 18, seed=70); wt = rnd(32, 16, 3, 3, seed=71, scale=0.1)
     wp = ops.pack_conv3x3(dev(wt))
     y = ops.conv3x3(dev(x), wp, 32)
-    key = ("conv3x3", 4, 12, 18, 16, 0, 32)
+    key = ("conv3x3", 4, 12, 18, 16, 0, 32, 1)
     assert key in ops.tuned_table()
     assert rel_l2(y, F.conv2d(x.double(), wt.double(), padding=1)) < TOL
+
+
+def test_conv3x3_split_k(ops):
+    """K (input-channel) split over workgroups: atomically accumulated partial sums + bias must match."""
+    n, ci, co, h, w = 3, 96, 40, 6, 9
+    x = rnd(n, ci, h, w, seed=80); wt = rnd(co, ci, 3, 3, seed=81, scale=(9 * ci) ** -0.5); b = rnd(co, seed=82)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    wp = ops.pack_conv3x3(dev(wt))
+    for cfg in (7, 10, 12):
+        for ks in (2, 3, 4, 12, 50):
+            y = ops.conv3x3(dev(x), wp, co, bias=dev(b), config=cfg + (ks << 8))
+            assert rel_l2(y, ref) < TOL, (cfg, ks)
+    buf = dev(rnd(n, co, h, w, seed=83))
+    from climate_amd._lib import lib
+    rc = lib.cm_conv3x3(dev(x).data_ptr(), ci * h * w, ci, None, 0, 0, wp.data_ptr(), None, buf.data_ptr(), co * h * w,
+                        buf.data_ptr(), co * h * w, n, h, w, co, 7 + (2 << 8), None)
+    assert rc == -22          # split-K with an in-place residual is refused
