@@ -35,6 +35,9 @@ long long cm_conv3x3_packed_elems(int k_channels, int out_channels);
  * dgrad=0: operand for y = conv(x, w).  dgrad=1: operand for dx = conv(dy, flip/transposed w). */
 int cm_pack_conv3x3(const float* w, int cout, int cin_total, int c_off, int cin, int dgrad, float* wp,
                     cm_stream stream);
+/* One launch for many cm_pack_conv3x3 jobs.  descs_dev: device array of (ndesc + 1) records of 8 int64
+ * {w ptr, wp ptr, cout, cin_total, c_off, cin, dgrad, first block}; record ndesc carries total_blocks in field 7. */
+int cm_pack_conv3x3_batch(const void* descs_dev, int ndesc, int total_blocks, cm_stream stream);
 /* out[n, :cout] = conv3x3(cat(in0[:, :c0], in1[:, :c1]), wp) (+ bias) (+ resid).  in1 may be NULL (c1 = 0).
  * resid (nullable) uses the addressing of out (st_resid must equal st_out; resid may alias out).
  * config < 0 picks a tile configuration automatically; else bits 0-7 = tile configuration, bits 8.. = split of
@@ -56,6 +59,8 @@ int cm_wgrad3x3(const float* x0, long long sx0, int c0, const float* x1, long lo
                 long long sdy, float* g, int ctot, int c_off, int n, int h, int w, int cout, int config,
                 cm_stream stream);
 int cm_wgrad3x3_unpack(const float* g, float* dw, int cout, int ctot, float scale, cm_stream stream);
+/* batched form: records of 8 int64 {g ptr, dw ptr, cout, ctot, 0, 0, 0, first block}, as cm_pack_conv3x3_batch */
+int cm_wgrad3x3_unpack_batch(const void* descs_dev, int ndesc, int total_blocks, float scale, cm_stream stream);
 
 /* ---- GroupNorm(8) + SiLU ----------------------------------------------------------------------------------- *
  * nn.GroupNorm(8, c), nn.SiLU: src/unet.py:37,39.  stats[n*groups+g] = {mean, rstd}.  pooled (nullable) receives

@@ -111,22 +111,34 @@ __global__ __launch_bounds__(256) void se_wgrad_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ spatial gate fwd
-// map[n,0,p] = mean_c(a2*s), map[n,1,p] = max_c(a2*s); one thread per pixel, coalesced along HW
-__global__ void spatial_stats_kernel(const float* __restrict__ a2, const float* __restrict__ s,
-                                     float* __restrict__ map, int C, int HW) {
+// map[n,0,p] = mean_c(a2*s), map[n,1,p] = max_c(a2*s).  Workgroup = 64 pixels x 4 channel slices (one wave each);
+// slices are combined through LDS in a fixed order (the max is order independent, the sum order is fixed).
+__global__ __launch_bounds__(256) void spatial_stats_kernel(const float* __restrict__ a2, const float* __restrict__ s,
+                                                             float* __restrict__ map, int C, int HW) {
+  __shared__ float ssum[4][64], smax[4][64];
   const int n = blockIdx.y;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= HW) return;
-  const float* ap = a2 + (long long)n * C * HW + p;
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int p = blockIdx.x * 64 + lane;
+  const bool live = p < HW;
+  const float* ap = a2 + (long long)n * C * HW + (live ? p : 0);
   const float* sp = s + (long long)n * C;
+  const int cper = (C + 3) / 4, c0 = slice * cper, c1 = min(C, c0 + cper);
   float sum = 0.f, mx = -INFINITY;
-  for (int c = 0; c < C; ++c) {
+#pragma unroll 8
+  for (int c = c0; c < c1; ++c) {
     const float u = ap[(long long)c * HW] * sp[c];
     sum += u;
     mx = fmaxf(mx, u);
   }
-  map[((long long)n * 2) * HW + p] = sum / (float)C;
-  map[((long long)n * 2 + 1) * HW + p] = mx;
+  ssum[slice][lane] = sum;
+  smax[slice][lane] = mx;
+  __syncthreads();
+  if (slice == 0 && live) {
+    const float t = ((ssum[0][lane] + ssum[1][lane]) + ssum[2][lane]) + ssum[3][lane];
+    const float m = fmaxf(fmaxf(smax[0][lane], smax[1][lane]), fmaxf(smax[2][lane], smax[3][lane]));
+    map[((long long)n * 2) * HW + p] = t / (float)C;
+    map[((long long)n * 2 + 1) * HW + p] = m;
+  }
 }
 
 __device__ __forceinline__ float conv7_at(const float* __restrict__ mp, const float* __restrict__ w7, int y, int x,
@@ -173,25 +185,41 @@ __global__ void spatial_apply_kernel(const float* __restrict__ a2, const float* 
 
 // ------------------------------------------------------------------------------------------------ spatial gate bwd
 // per pixel: dgate = sum_c dout*U; dgpre = dgate*gate*(1-gate); cnt = #{c: U == max}
-__global__ void gate_bwd_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ a2,
-                                       const float* __restrict__ s, const float* __restrict__ gate,
-                                       const float* __restrict__ map, float* __restrict__ dgpre,
-                                       float* __restrict__ cnt, int C, int HW) {
+// Workgroup = 64 pixels x 4 channel slices, combined through LDS.
+__global__ __launch_bounds__(256) void gate_bwd_reduce_kernel(const float* __restrict__ dout,
+                                                               const float* __restrict__ a2,
+                                                               const float* __restrict__ s,
+                                                               const float* __restrict__ gate,
+                                                               const float* __restrict__ map,
+                                                               float* __restrict__ dgpre, float* __restrict__ cnt,
+                                                               int C, int HW) {
+  __shared__ float sdg[4][64], scn[4][64];
   const int n = blockIdx.y;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= HW) return;
-  const float mx = map[((long long)n * 2 + 1) * HW + p];
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int p = blockIdx.x * 64 + lane;
+  const bool live = p < HW;
+  const int pp = live ? p : 0;
+  const float mx = map[((long long)n * 2 + 1) * HW + pp];
   const float* sp = s + (long long)n * C;
+  const int cper = (C + 3) / 4, c0 = slice * cper, c1 = min(C, c0 + cper);
   float dg = 0.f, k = 0.f;
-  for (int c = 0; c < C; ++c) {
-    const long long i = ((long long)n * C + c) * HW + p;
+#pragma unroll 8
+  for (int c = c0; c < c1; ++c) {
+    const long long i = ((long long)n * C + c) * HW + pp;
     const float u = a2[i] * sp[c];
     dg += dout[i] * u;
     k += (u == mx) ? 1.f : 0.f;
   }
-  const float g = gate[(long long)n * HW + p];
-  dgpre[(long long)n * HW + p] = dg * g * (1.f - g);
-  cnt[(long long)n * HW + p] = k;
+  sdg[slice][lane] = dg;
+  scn[slice][lane] = k;
+  __syncthreads();
+  if (slice == 0 && live) {
+    const float t = ((sdg[0][lane] + sdg[1][lane]) + sdg[2][lane]) + sdg[3][lane];
+    const float kk = (scn[0][lane] + scn[1][lane]) + (scn[2][lane] + scn[3][lane]);
+    const float g = gate[(long long)n * HW + p];
+    dgpre[(long long)n * HW + p] = t * g * (1.f - g);
+    cnt[(long long)n * HW + p] = kk;
+  }
 }
 
 // dmap[n,ch,p] = sum_taps dgpre[n, p - (tap-3)] * w7[ch][tap];  dW7[ch][tap] += sum_{n,p} map[n,ch,p+tap-3]*dgpre[n,p]
@@ -301,8 +329,7 @@ int cm_se_excite_bwd(const float* ds, const float* s, const float* z, const floa
 
 int cm_spatial_stats(const float* a2, const float* s, float* map, int n, int c, int hw, cm_stream stream) {
   if (n <= 0 || c <= 0 || hw <= 0) return -22;
-  const int bs = hw >= 256 ? 256 : 64;
-  spatial_stats_kernel<<<dim3(cdiv(hw, bs), n), bs, 0, (hipStream_t)stream>>>(a2, s, map, c, hw);
+  spatial_stats_kernel<<<dim3(cdiv(hw, 64), n), 256, 0, (hipStream_t)stream>>>(a2, s, map, c, hw);
   CM_CHECK_LAUNCH();
   return 0;
 }
@@ -325,9 +352,8 @@ int cm_spatial_apply(const float* a2, const float* s, const float* map, const fl
 int cm_gate_bwd_reduce(const float* dout, const float* a2, const float* s, const float* gate, const float* map,
                        float* dgpre, float* cnt, int n, int c, int hw, cm_stream stream) {
   if (n <= 0 || c <= 0 || hw <= 0) return -22;
-  const int bs = hw >= 256 ? 256 : 64;
-  gate_bwd_reduce_kernel<<<dim3(cdiv(hw, bs), n), bs, 0, (hipStream_t)stream>>>(dout, a2, s, gate, map, dgpre, cnt, c,
-                                                                                hw);
+  gate_bwd_reduce_kernel<<<dim3(cdiv(hw, 64), n), 256, 0, (hipStream_t)stream>>>(dout, a2, s, gate, map, dgpre, cnt, c,
+                                                                                  hw);
   CM_CHECK_LAUNCH();
   return 0;
 }

@@ -21,6 +21,8 @@
 
 namespace {
 
+constexpr int KCH_PACK = 8;   // == KCH below (K-chunk of the conv kernel)
+
 struct Conv3Args {
   const float* in0;
   const float* in1;
@@ -278,6 +280,34 @@ __global__ void zero_out_kernel(float* __restrict__ out, long long sto, int n, l
     out[(i / per) * sto + (i % per)] = 0.f;
 }
 
+// Batched packer: one launch re-packs every 3x3 weight of the model.  descs = (ndesc + 1) records of 8 int64:
+// {w ptr, wp ptr, cout, cin_total, c_off, cin, dgrad, first block}; the last record only carries the total block count.
+__global__ void pack_batch_kernel(const long long* __restrict__ descs, int ndesc) {
+  int d = 0;
+  while (d + 1 < ndesc && descs[(d + 1) * 8 + 7] <= (long long)blockIdx.x) ++d;
+  const long long* r = descs + d * 8;
+  const float* w = reinterpret_cast<const float*>(r[0]);
+  float* wp = reinterpret_cast<float*>(r[1]);
+  const int cout = (int)r[2], cin_total = (int)r[3], c_off = (int)r[4], cin = (int)r[5], dgrad = (int)r[6];
+  const int b0 = (int)r[7], nb = (int)descs[(d + 1) * 8 + 7] - b0;
+  const int kch = dgrad ? cout : cin, ocs = dgrad ? cin : cout;
+  const int rowsP = ((kch + KCH_PACK - 1) / KCH_PACK) * KCH_PACK, colsP = ((ocs + 31) / 32) * 32;
+  const long long total = (long long)rowsP * 9 * colsP;
+  for (long long i = (long long)(blockIdx.x - b0) * blockDim.x + threadIdx.x; i < total; i += (long long)nb * blockDim.x) {
+    const int col = (int)(i % colsP);
+    const int row = (int)(i / colsP);
+    const int par = row & 1, rt = row >> 1;
+    const int tap = rt % 9, kc = (rt / 9) * 2 + par;
+    float v = 0.f;
+    if (!dgrad) {
+      if (kc < cin && col < cout) v = w[((long long)col * cin_total + c_off + kc) * 9 + tap];
+    } else {
+      if (kc < cout && col < cin) v = w[((long long)kc * cin_total + c_off + col) * 9 + (8 - tap)];
+    }
+    wp[i] = v;
+  }
+}
+
 struct TileCfg {
   int th, tw, s, waves, npt, wm;
 };
@@ -384,6 +414,13 @@ int cm_pack_conv3x3(const float* w, int cout, int cin_total, int c_off, int cin,
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   pack_conv3x3_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(w, wp, cout, cin_total, c_off, cin, rowsP, colsP,
                                                                dgrad);
+  CM_CHECK_LAUNCH();
+  return 0;
+}
+
+int cm_pack_conv3x3_batch(const void* descs_dev, int ndesc, int total_blocks, cm_stream stream) {
+  if (ndesc <= 0 || total_blocks <= 0) return -22;
+  pack_batch_kernel<<<total_blocks, 256, 0, (hipStream_t)stream>>>((const long long*)descs_dev, ndesc);
   CM_CHECK_LAUNCH();
   return 0;
 }

@@ -49,41 +49,72 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred
 }
 
 // dx[n,c,p] = sum_o W[o][c] dpred[n,o,p]; dW[o][c] += sum_{n,p} dpred x; db[o] += sum dpred
+// A workgroup walks `ppb` pixels of one sample; per 16-channel chunk every thread keeps its dW partials in registers
+// over all its pixels and the cross-lane reduction happens once per (o, c), not once per pixel tile.
+constexpr int HB_CC = 16;
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dpred, const float* __restrict__ x,
                                                         long long sx, const float* __restrict__ w,
                                                         float* __restrict__ dx, long long sdx,
                                                         float* __restrict__ dw, float* __restrict__ db, int C,
-                                                        int OC, int HW, int tiles_per_block) {
+                                                        int OC, int HW, int ppb) {
   extern __shared__ float sh[];  // [OC*C] dW partial + [OC] db partial
   const int tid = threadIdx.x, lane = tid & 63;
   const int n = blockIdx.y;
+  const int p_begin = blockIdx.x * ppb, p_end = min(HW, p_begin + ppb);
   for (int i = tid; i < OC * C + OC; i += 256) sh[i] = 0.f;
   __syncthreads();
-  for (int tl = 0; tl < tiles_per_block; ++tl) {
-    const int p = (blockIdx.x * tiles_per_block + tl) * 256 + tid;
-    const bool ok = p < HW;
-    float dp[MAXOC];
+  float dbp[MAXOC];
 #pragma unroll
-    for (int o = 0; o < MAXOC; ++o) dp[o] = (ok && o < OC) ? dpred[((long long)n * OC + o) * HW + p] : 0.f;
+  for (int o = 0; o < MAXOC; ++o) dbp[o] = 0.f;
+  for (int c0 = 0; c0 < C; c0 += HB_CC) {
+    float dwp[MAXOC][HB_CC];
+#pragma unroll
+    for (int o = 0; o < MAXOC; ++o)
+#pragma unroll
+      for (int j = 0; j < HB_CC; ++j) dwp[o][j] = 0.f;
+    for (int p = p_begin + tid; p < p_end; p += 256) {
+      float dp[MAXOC];
+#pragma unroll
+      for (int o = 0; o < MAXOC; ++o) dp[o] = (o < OC) ? dpred[((long long)n * OC + o) * HW + p] : 0.f;
+      if (c0 == 0) {
+#pragma unroll
+        for (int o = 0; o < MAXOC; ++o) dbp[o] += dp[o];
+      }
+#pragma unroll
+      for (int j = 0; j < HB_CC; ++j) {
+        const int c = c0 + j;
+        if (c < C) {
+          const float xv = x[(long long)n * sx + (long long)c * HW + p];
+          float g = 0.f;
+#pragma unroll
+          for (int o = 0; o < MAXOC; ++o) {
+            if (o < OC) {
+              g += w[o * C + c] * dp[o];
+              dwp[o][j] += dp[o] * xv;
+            }
+          }
+          dx[(long long)n * sdx + (long long)c * HW + p] = g;
+        }
+      }
+    }
 #pragma unroll
     for (int o = 0; o < MAXOC; ++o) {
       if (o < OC) {
-        const float s = wave_sum(dp[o]);
-        if (lane == 0) atomicAdd(&sh[OC * C + o], s);
-      }
-    }
-    for (int c = 0; c < C; ++c) {
-      const float xv = ok ? x[(long long)n * sx + (long long)c * HW + p] : 0.f;
-      float g = 0.f;
 #pragma unroll
-      for (int o = 0; o < MAXOC; ++o) {
-        if (o < OC) {
-          g += w[o * C + c] * dp[o];
-          const float s = wave_sum(dp[o] * xv);
-          if (lane == 0) atomicAdd(&sh[o * C + c], s);
+        for (int j = 0; j < HB_CC; ++j) {
+          if (c0 + j < C) {
+            const float sred = wave_sum(dwp[o][j]);
+            if (lane == 0) atomicAdd(&sh[o * C + c0 + j], sred);
+          }
         }
       }
-      if (ok) dx[(long long)n * sdx + (long long)c * HW + p] = g;
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < MAXOC; ++o) {
+    if (o < OC) {
+      const float sred = wave_sum(dbp[o]);
+      if (lane == 0) atomicAdd(&sh[OC * C + o], sred);
     }
   }
   __syncthreads();
@@ -117,10 +148,11 @@ int cm_mse_loss(const float* pred, const float* y, float* loss, float* dpred, lo
 int cm_head_bwd(const float* dpred, const float* x, long long sx, const float* w, float* dx, long long sdx, float* dw,
                 float* db, int n, int c, int oc, int hw, cm_stream stream) {
   if (n <= 0 || c <= 0 || oc <= 0 || oc > MAXOC || hw <= 0) return -22;
-  const int tiles = cdiv(hw, 256);
-  const int tpb = tiles >= 8 ? 4 : 1;
-  head_bwd_kernel<<<dim3(cdiv(tiles, tpb), n), 256, (oc * c + oc) * sizeof(float), (hipStream_t)stream>>>(
-      dpred, x, sx, w, dx, sdx, dw, db, c, oc, hw, tpb);
+  int parts = 1;
+  while (n * parts < 256 && hw / (parts * 2) >= 256) parts *= 2;   // >= 256 pixels per workgroup
+  const int ppb = cdiv(hw, parts);
+  head_bwd_kernel<<<dim3(cdiv(hw, ppb), n), 256, (oc * c + oc) * sizeof(float), (hipStream_t)stream>>>(
+      dpred, x, sx, w, dx, sdx, dw, db, c, oc, hw, ppb);
   CM_CHECK_LAUNCH();
   return 0;
 }

@@ -16,10 +16,17 @@ namespace {
 
 constexpr int GN_THREADS = 256;
 
+template <int LPC>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = LPC / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
 // sigmoid with the hardware exp / rcp (v_exp_f32, v_rcp_f32): ~1e-7 relative, far inside the 1e-4 parity budget
 __device__ __forceinline__ float fast_sigmoid(float u) { return __frcp_rn(1.f + __expf(-u)); }
 
-template <bool VEC>
+template <bool VEC, int LPC>   // LPC lanes cooperate on one channel (64: a wave, 16: four channels per wave)
 __global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_kernel(const float* __restrict__ x,
                                                                    const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta,
@@ -64,9 +71,9 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_kernel(const float* __
     stats[2 * blockIdx.x + 1] = rstd;
   }
 
-  // apply: one wave per channel so the per-channel mean of the output falls out of a wave reduction
-  const int lane = tid & 63, wave = tid >> 6;
-  for (int cl = wave; cl < cpg; cl += GN_THREADS / 64) {
+  // apply: LPC lanes per channel so the per-channel mean of the output falls out of a sub-wave reduction
+  const int lane = tid % LPC, wave = tid / LPC;
+  for (int cl = wave; cl < cpg; cl += GN_THREADS / LPC) {
     const int c = g * cpg + cl;
     const float ga = gamma[c] * rstd, be = beta[c] - mean * rstd * gamma[c];
     const float* xc = xg + (long long)cl * HW;
@@ -75,7 +82,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_kernel(const float* __
     if (VEC) {
       const float4* x4 = reinterpret_cast<const float4*>(xc);
       float4* y4 = reinterpret_cast<float4*>(yc);
-      for (int i = lane; i < HW / 4; i += 64) {
+      for (int i = lane; i < HW / 4; i += LPC) {
         const float4 v = x4[i];
         float4 o;
         float u;
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_kernel(const float* __
         ps += (o.x + o.y) + (o.z + o.w);
       }
     } else {
-      for (int i = lane; i < HW; i += 64) {
+      for (int i = lane; i < HW; i += LPC) {
         const float u = xc[i] * ga + be;
         const float o = u * fast_sigmoid(u);
         yc[i] = o;
@@ -95,7 +102,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_kernel(const float* __
       }
     }
     if (pooled) {
-      ps = wave_sum(ps);
+      ps = group_sum<LPC>(ps);
       if (lane == 0) pooled[(long long)n * C + c] = ps / (float)HW;
     }
   }
@@ -117,7 +124,7 @@ struct GateBwd {
 //   pass 1: du = upstream * silu'(u) is written to dx (scratch use of the output buffer) while the per-channel and
 //           per-group sums are accumulated;  pass 2: dx = rstd * (du*gamma - s1 - xhat*s2) in place (du comes back
 //           from L2).  MODE 0: upstream gradient given as a tensor; MODE 1: rebuilt from the gate backward maps.
-template <int MODE, int V>   // V = 4: float4 path (HW % 4 == 0), V = 1: scalar
+template <int MODE, int V, int LPC>   // V = 4: float4 path (HW % 4 == 0), V = 1: scalar; LPC lanes per channel
 __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_kernel(const float* __restrict__ x,
                                                                    const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta,
@@ -129,7 +136,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_kernel(const float* __
   __shared__ float acc[2];
   const int n = blockIdx.x / G, g = blockIdx.x % G;
   const int cpg = C / G;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid % LPC, wave = tid / LPC;
   const float mean = stats[2 * blockIdx.x], rstd = stats[2 * blockIdx.x + 1];
   const float inv_hw = 1.f / (float)HW, inv_c = 1.f / (float)C;
   if (tid < 2) acc[tid] = 0.f;
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_kernel(const float* __
   typedef float vec_t __attribute__((ext_vector_type(V)));
   const int HWV = HW / V;
 
-  for (int cl = wave; cl < cpg; cl += GN_THREADS / 64) {
+  for (int cl = wave; cl < cpg; cl += GN_THREADS / LPC) {
     const int c = g * cpg + cl;
     const float ga = gamma[c], be = beta[c];
     const long long nc = (long long)n * C + c;
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_kernel(const float* __
     const float sc = MODE == 1 ? gb.s[nc] : 0.f;
     const float dpl = MODE == 1 ? gb.dpool[nc] * inv_hw : 0.f;
     float sd = 0.f, sdx = 0.f;
-    for (int i = lane; i < HWV; i += 64) {
+    for (int i = lane; i < HWV; i += LPC) {
       const vec_t xv = xc[i];
       vec_t up;
       if (MODE == 0) {
@@ -183,8 +190,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_kernel(const float* __
       }
       dxc[i] = duv;
     }
-    sd = wave_sum(sd);
-    sdx = wave_sum(sdx);
+    sd = group_sum<LPC>(sd);
+    sdx = group_sum<LPC>(sdx);
     if (lane == 0) {
       unsafeAtomicAdd(dbeta + c, sd);
       unsafeAtomicAdd(dgamma + c, sdx);
@@ -196,13 +203,13 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_kernel(const float* __
   const float m = 1.f / (float)(cpg * HW);
   const float s1 = acc[0] * m, s2 = acc[1] * m;
 
-  for (int cl = wave; cl < cpg; cl += GN_THREADS / 64) {
+  for (int cl = wave; cl < cpg; cl += GN_THREADS / LPC) {
     const int c = g * cpg + cl;
     const float ga = gamma[c];
     const long long nc = (long long)n * C + c;
     const vec_t* xc = reinterpret_cast<const vec_t*>(x + nc * HW);
     vec_t* dxc = reinterpret_cast<vec_t*>(dx + nc * HW);
-    for (int i = lane; i < HWV; i += 64) {
+    for (int i = lane; i < HWV; i += LPC) {
       const vec_t xv = xc[i];
       vec_t dv = dxc[i];
 #pragma unroll
@@ -223,12 +230,12 @@ int cm_gn_silu_fwd(const float* x, const float* gamma, const float* beta, float*
                    int n, int c, int hw, int groups, float eps, cm_stream stream) {
   if (n <= 0 || c <= 0 || hw <= 0 || groups <= 0 || c % groups) return -22;
   const bool vec = (hw % 4) == 0;
-  if (vec)
-    gn_silu_fwd_kernel<true><<<n * groups, GN_THREADS, 0, (hipStream_t)stream>>>(x, gamma, beta, y, stats, pooled, c,
-                                                                                  hw, groups, eps);
-  else
-    gn_silu_fwd_kernel<false><<<n * groups, GN_THREADS, 0, (hipStream_t)stream>>>(x, gamma, beta, y, stats, pooled,
-                                                                                   c, hw, groups, eps);
+  const bool narrow = (vec ? hw / 4 : hw) <= 64 && (c / groups) >= 8;   // short rows: 16 lanes per channel
+  hipStream_t st = (hipStream_t)stream;
+#define GN_FWD(V, L) gn_silu_fwd_kernel<V, L><<<n * groups, GN_THREADS, 0, st>>>(x, gamma, beta, y, stats, pooled, c, hw, groups, eps)
+  if (vec) { if (narrow) GN_FWD(true, 16); else GN_FWD(true, 64); }
+  else     { if (narrow) GN_FWD(false, 16); else GN_FWD(false, 64); }
+#undef GN_FWD
   CM_CHECK_LAUNCH();
   return 0;
 }
@@ -238,12 +245,13 @@ int cm_gn_silu_bwd(const float* x, const float* gamma, const float* beta, const 
                    cm_stream stream) {
   if (n <= 0 || c <= 0 || hw <= 0 || groups <= 0 || c % groups) return -22;
   GateBwd gb = {};
-  if ((hw % 4) == 0 && (st_dA % 4) == 0)
-    gn_silu_bwd_kernel<0, 4><<<n * groups, GN_THREADS, 0, (hipStream_t)stream>>>(x, gamma, beta, stats, dA, st_dA, gb,
-                                                                                 dx, dgamma, dbeta, c, hw, groups);
-  else
-    gn_silu_bwd_kernel<0, 1><<<n * groups, GN_THREADS, 0, (hipStream_t)stream>>>(x, gamma, beta, stats, dA, st_dA, gb,
-                                                                                 dx, dgamma, dbeta, c, hw, groups);
+  const bool vec = (hw % 4) == 0 && (st_dA % 4) == 0;
+  const bool narrow = (vec ? hw / 4 : hw) <= 64 && (c / groups) >= 8;
+  hipStream_t st = (hipStream_t)stream;
+#define GN_BWD(V, L) gn_silu_bwd_kernel<0, V, L><<<n * groups, GN_THREADS, 0, st>>>(x, gamma, beta, stats, dA, st_dA, gb, dx, dgamma, dbeta, c, hw, groups)
+  if (vec) { if (narrow) GN_BWD(4, 16); else GN_BWD(4, 64); }
+  else     { if (narrow) GN_BWD(1, 16); else GN_BWD(1, 64); }
+#undef GN_BWD
   CM_CHECK_LAUNCH();
   return 0;
 }
@@ -255,12 +263,13 @@ int cm_gn_silu_bwd_gated(const float* x, const float* gamma, const float* beta, 
   if (n <= 0 || c <= 0 || hw <= 0 || groups <= 0 || c % groups) return -22;
   GateBwd gb;
   gb.a2 = a2; gb.dout = dout; gb.gate = gate; gb.dmap = dmap; gb.umax = fmap; gb.cnt = cnt; gb.s = s; gb.dpool = dpool;
-  if ((hw % 4) == 0)
-    gn_silu_bwd_kernel<1, 4><<<n * groups, GN_THREADS, 0, (hipStream_t)stream>>>(x, gamma, beta, stats, nullptr, 0, gb,
-                                                                                 dx, dgamma, dbeta, c, hw, groups);
-  else
-    gn_silu_bwd_kernel<1, 1><<<n * groups, GN_THREADS, 0, (hipStream_t)stream>>>(x, gamma, beta, stats, nullptr, 0, gb,
-                                                                                 dx, dgamma, dbeta, c, hw, groups);
+  const bool vec = (hw % 4) == 0;
+  const bool narrow = (vec ? hw / 4 : hw) <= 64 && (c / groups) >= 8;
+  hipStream_t st = (hipStream_t)stream;
+#define GN_BWD(V, L) gn_silu_bwd_kernel<1, V, L><<<n * groups, GN_THREADS, 0, st>>>(x, gamma, beta, stats, nullptr, 0, gb, dx, dgamma, dbeta, c, hw, groups)
+  if (vec) { if (narrow) GN_BWD(4, 16); else GN_BWD(4, 64); }
+  else     { if (narrow) GN_BWD(1, 16); else GN_BWD(1, 64); }
+#undef GN_BWD
   CM_CHECK_LAUNCH();
   return 0;
 }

@@ -78,14 +78,18 @@ __global__ void time_mean_kernel(const float* __restrict__ x, float* __restrict_
 }
 
 // per-channel sum over samples and pixels: out[c] += sum_{n,p} x[n, c, p]   (bias gradients)
+// (n, p) is walked as one flat index so that small images still fill the workgroup.
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, long long st,
                                                            float* __restrict__ out, int N, int HW, int nsplit) {
   __shared__ float red[32];
   const int c = blockIdx.x, sp = blockIdx.y;
+  const long long total = (long long)N * HW;
+  const float* xc = x + (long long)c * HW;
   float a = 0.f;
-  for (int n = sp; n < N; n += nsplit) {
-    const float* p = x + (long long)n * st + (long long)c * HW;
-    for (int i = threadIdx.x; i < HW; i += 256) a += p[i];
+  for (long long i = sp * 256 + threadIdx.x; i < total; i += (long long)nsplit * 256) {
+    const long long n = i / HW;
+    const int p = (int)(i - n * HW);
+    a += xc[n * st + p];
   }
   a = block_sum(a, red);
   if (threadIdx.x == 0) unsafeAtomicAdd(out + c, a);
@@ -126,7 +130,7 @@ int cm_time_mean(const float* x, float* y, int b, int t, long long chw, cm_strea
 int cm_channel_sum(const float* x, long long st, float* out, int n, int c, int hw, cm_stream stream) {
   if (n <= 0 || c <= 0 || hw <= 0) return -22;
   int nsplit = 1;
-  while (c * nsplit < 512 && nsplit < n) nsplit *= 2;
+  while (c * nsplit < 1024 && (long long)nsplit * 256 * 8 < (long long)n * hw) nsplit *= 2;
   channel_sum_kernel<<<dim3(c, nsplit), 256, 0, (hipStream_t)stream>>>(x, st, out, n, hw, nsplit);
   CM_CHECK_LAUNCH();
   return 0;

@@ -240,6 +240,25 @@ __global__ void wgrad_unpack_kernel(const float* __restrict__ g, float* __restri
   }
 }
 
+// Batched unpack: descs = (ndesc + 1) records of 8 int64 {g ptr, dw ptr, cout, ctot, -, -, -, first block}.
+__global__ void wgrad_unpack_batch_kernel(const long long* __restrict__ descs, int ndesc, float scale) {
+  int d = 0;
+  while (d + 1 < ndesc && descs[(d + 1) * 8 + 7] <= (long long)blockIdx.x) ++d;
+  const long long* r = descs + d * 8;
+  const float* g = reinterpret_cast<const float*>(r[0]);
+  float* dw = reinterpret_cast<float*>(r[1]);
+  const int cout = (int)r[2], ctot = (int)r[3];
+  const int b0 = (int)r[7], nb = (int)descs[(d + 1) * 8 + 7] - b0;
+  const long long total = (long long)cout * ctot * 9;
+  for (long long i = (long long)(blockIdx.x - b0) * blockDim.x + threadIdx.x; i < total; i += (long long)nb * blockDim.x) {
+    const int tap = (int)(i % 9);
+    const long long oc = i / 9;
+    const int c = (int)(oc % ctot);
+    const int o = (int)(oc / ctot);
+    dw[i] = scale * g[((long long)o * 9 + tap) * ctot + c];
+  }
+}
+
 struct WgCfg {
   int th, tw, s, mo, ks;
 };
@@ -352,6 +371,13 @@ int cm_wgrad3x3(const float* x0, long long sx0, int c0, const float* x1, long lo
   if ((config >> 8) > 0) a.units_per_block = config >> 8;   // bits 8.. = grid size in quarter rounds of resident slots
   config &= 0xff;
   return c1 > 0 ? dispatch_wg<true>(config, a, (hipStream_t)stream) : dispatch_wg<false>(config, a, (hipStream_t)stream);
+}
+
+int cm_wgrad3x3_unpack_batch(const void* descs_dev, int ndesc, int total_blocks, float scale, cm_stream stream) {
+  if (ndesc <= 0 || total_blocks <= 0) return -22;
+  wgrad_unpack_batch_kernel<<<total_blocks, 256, 0, (hipStream_t)stream>>>((const long long*)descs_dev, ndesc, scale);
+  CM_CHECK_LAUNCH();
+  return 0;
 }
 
 int cm_wgrad3x3_unpack(const float* g, float* dw, int cout, int ctot, float scale, cm_stream stream) {

@@ -27,23 +27,105 @@ class _BlockCtx:
     __slots__ = ("x0", "x1", "y1", "a1", "st1", "y2", "a2", "st2", "pooled", "z", "s", "fmap", "gate", "out")
 
 
-def pack_weights(p: Params, need_input_grad: bool = False) -> Dict[str, Tensor]:
-    """MFMA operand layouts of every 3x3 weight: forward and data-gradient forms (re-run whenever params change)."""
-    pk: Dict[str, Tensor] = {}
+def _conv_jobs(p: Params, need_input_grad: bool):
+    """(key, weight name, c_off, cin, dgrad) for every MFMA operand the step needs."""
+    jobs = []
     for name, w in p.items():
-        if not (name.endswith("body.0.weight") or name.endswith("body.3.weight")):
-            continue
-        pk[name + "/f"] = ops.pack_conv3x3(w)
-        if name != "enc1.body.0.weight" or need_input_grad:
-            pk[name + "/d"] = ops.pack_conv3x3(w, dgrad=True)
+        if name.endswith("body.0.weight") or name.endswith("body.3.weight"):
+            jobs.append((name + "/f", name, 0, w.shape[1], 0))
+            if name != "enc1.body.0.weight" or need_input_grad:
+                jobs.append((name + "/d", name, 0, w.shape[1], 1))
     wl = p["convlstm.cell.conv.weight"]
     ch = wl.shape[0] // 4
     cx = wl.shape[1] - ch
-    pk["lstm.x/f"] = ops.pack_conv3x3(wl, c_off=0, cin=cx)
-    pk["lstm.h/f"] = ops.pack_conv3x3(wl, c_off=cx, cin=ch)
-    pk["lstm.x/d"] = ops.pack_conv3x3(wl, c_off=0, cin=cx, dgrad=True)
-    pk["lstm.h/d"] = ops.pack_conv3x3(wl, c_off=cx, cin=ch, dgrad=True)
-    return pk
+    for key, off, cin, dg in (("lstm.x/f", 0, cx, 0), ("lstm.h/f", cx, ch, 0), ("lstm.x/d", 0, cx, 1),
+                              ("lstm.h/d", cx, ch, 1)):
+        jobs.append((key, "convlstm.cell.conv.weight", off, cin, dg))
+    return jobs
+
+
+class Plan:
+    """Persistent per-model scratch: the packed-weight arena + its batched pack job table, and (for training) the
+    tap-major weight-gradient staging arena + its batched unpack table.  One launch each per step for pack, zero
+    and unpack instead of ~60 tiny ones.  Valid while the parameter / gradient storage addresses stay the same."""
+
+    def __init__(self, p: Params, g: Optional[Params], need_input_grad: bool):
+        from ._lib import lib
+        dev = p["head.weight"].device
+        self.key = self.signature(p, g, need_input_grad)
+        jobs = _conv_jobs(p, need_input_grad)
+        sizes = []
+        for key, name, off, cin, dg in jobs:
+            w = p[name]
+            sizes.append(lib.cm_conv3x3_packed_elems(w.shape[0] if dg else cin, cin if dg else w.shape[0]))
+        self.wp_arena = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
+        self.pk: Dict[str, Tensor] = {}
+        rec, o, blk = [], 0, 0
+        for (key, name, off, cin, dg), sz in zip(jobs, sizes):
+            w = p[name]
+            if not w.is_contiguous():
+                raise RuntimeError("parameters must be contiguous")
+            self.pk[key] = self.wp_arena[o:o + sz]
+            rec.append([w.data_ptr(), self.pk[key].data_ptr(), w.shape[0], w.shape[1], off, cin, dg, blk])
+            blk += max(1, min(64, (sz + 2047) // 2048))
+            o += sz
+        rec.append([0, 0, 0, 0, 0, 0, 0, blk])
+        self.pack_table = torch.tensor(rec, dtype=torch.int64).to(dev)
+        self.pack_n, self.pack_blocks = len(jobs), blk
+        self.gw: Dict[str, Tensor] = {}
+        if g is not None:
+            names = [n for n in p if n.endswith("body.0.weight") or n.endswith("body.3.weight")]
+            names.append("convlstm.cell.conv.weight")
+            total = sum(p[n].numel() for n in names)
+            self.g_arena = torch.empty(total, device=dev, dtype=torch.float32)
+            rec, o, blk = [], 0, 0
+            for n in names:
+                co, ci = p[n].shape[0], p[n].shape[1]
+                sz = p[n].numel()
+                self.gw[n] = self.g_arena[o:o + sz].view(co, 9, ci)
+                rec.append([self.gw[n].data_ptr(), g[n].data_ptr(), co, ci, 0, 0, 0, blk])
+                blk += max(1, min(64, (sz + 2047) // 2048))
+                o += sz
+            rec.append([0, 0, 0, 0, 0, 0, 0, blk])
+            self.unpack_table = torch.tensor(rec, dtype=torch.int64).to(dev)
+            self.unpack_n, self.unpack_blocks = len(names), blk
+
+    @staticmethod
+    def signature(p: Params, g: Optional[Params], need_input_grad: bool):
+        return (tuple(t.data_ptr() for t in p.values()), None if g is None else tuple(t.data_ptr() for t in g.values()),
+                bool(need_input_grad))
+
+    def pack(self):
+        from ._lib import check, lib
+        check(lib.cm_pack_conv3x3_batch(self.pack_table.data_ptr(), self.pack_n, self.pack_blocks,
+                                        torch.cuda.current_stream().cuda_stream), "pack_batch")
+        return self.pk
+
+    def zero_staging(self):
+        _zero_(self.g_arena)
+
+    def unpack(self):
+        from ._lib import check, lib
+        check(lib.cm_wgrad3x3_unpack_batch(self.unpack_table.data_ptr(), self.unpack_n, self.unpack_blocks, 1.0,
+                                           torch.cuda.current_stream().cuda_stream), "unpack_batch")
+
+
+_PLANS: Dict[tuple, Plan] = {}
+
+
+def get_plan(p: Params, g: Optional[Params] = None, need_input_grad: bool = False) -> Plan:
+    key = Plan.signature(p, g, need_input_grad)
+    plan = _PLANS.get(key)
+    if plan is None:
+        if len(_PLANS) > 8:
+            _PLANS.clear()
+        plan = _PLANS[key] = Plan(p, g, need_input_grad)
+    return plan
+
+
+def pack_weights(p: Params, need_input_grad: bool = False) -> Dict[str, Tensor]:
+    """MFMA operand layouts of every 3x3 weight: forward and data-gradient forms (re-run whenever params change)."""
+    return get_plan(p, None, need_input_grad).pack()
 
 
 # ------------------------------------------------------------------------------------------------- ConvBlock
@@ -63,7 +145,7 @@ def _block_fwd(p: Params, pk, prefix: str, x0: Tensor, x1: Optional[Tensor], sav
     return out, ctx
 
 
-def _block_bwd(p: Params, pk, g: Params, prefix: str, ctx: _BlockCtx, dout: Tensor, need_dx: bool = True):
+def _block_bwd(p: Params, pk, g: Params, gw: Params, prefix: str, ctx: _BlockCtx, dout: Tensor, need_dx: bool = True):
     """Returns d(input) as one tensor [N, C0+C1, H, W] (or None); parameter gradients are accumulated into ``g``."""
     co = ctx.y1.shape[1]
     w1, w2, w7 = p[prefix + "se.fc.0.weight"], p[prefix + "se.fc.2.weight"], p[prefix + "spat.conv.weight"]
@@ -73,16 +155,12 @@ def _block_bwd(p: Params, pk, g: Params, prefix: str, ctx: _BlockCtx, dout: Tens
     dy2 = ops.gn_silu_bwd_gated(ctx.y2, p[prefix + "body.4.weight"], p[prefix + "body.4.bias"], ctx.st2, ctx.a2, dout,
                                 ctx.gate, dmap, ctx.fmap, cnt, ctx.s, dpool, g[prefix + "body.4.weight"],
                                 g[prefix + "body.4.bias"])
-    gw = _zeros(co, 9, co, device=dout.device)
-    ops.wgrad3x3(ctx.a1, dy2, gw)
-    _unpack_into(gw, g[prefix + "body.3.weight"])
+    ops.wgrad3x3(ctx.a1, dy2, gw[prefix + "body.3.weight"])
     da1 = ops.conv3x3(dy2, pk[prefix + "body.3.weight/d"], co)
     dy1 = ops.gn_silu_bwd(ctx.y1, p[prefix + "body.1.weight"], p[prefix + "body.1.bias"], ctx.st1, da1,
                           g[prefix + "body.1.weight"], g[prefix + "body.1.bias"])
     ci = ctx.x0.shape[1] + (0 if ctx.x1 is None else ctx.x1.shape[1])
-    gw = _zeros(co, 9, ci, device=dout.device)
-    ops.wgrad3x3(ctx.x0, dy1, gw, x1=ctx.x1)
-    _unpack_into(gw, g[prefix + "body.0.weight"])
+    ops.wgrad3x3(ctx.x0, dy1, gw[prefix + "body.0.weight"], x1=ctx.x1)
     if not need_dx:
         return None
     return ops.conv3x3(dy1, pk[prefix + "body.0.weight/d"], ci)
@@ -173,6 +251,9 @@ def forward(p: Params, pk, x_seq: Tensor, save: bool = True):
 def backward(p: Params, pk, g: Params, sv: Saved, dpred: Tensor, need_dx: bool = False):
     """Accumulates every parameter gradient into ``g`` (same keys as ``p``; the caller zeroes them) and returns
     d(x_seq) when ``need_dx``.  ``post_conv.*`` is untouched (never used by the forward, as in the reference)."""
+    plan = get_plan(p, g, need_dx)
+    gw = plan.gw
+    plan.zero_staging()
     B, T = sv.B, sv.T
     c1, c2, c3, c4 = sv.enc
     cu3, cu2, cu1 = sv.ups
@@ -180,13 +261,13 @@ def backward(p: Params, pk, g: Params, sv: Saved, dpred: Tensor, need_dx: bool =
 
     # ---- head + decoder --------------------------------------------------------------------------------
     dd1 = ops.head_bwd(dpred, sv.d1, p["head.weight"], g["head.weight"], g["head.bias"])
-    dcat1 = _block_bwd(p, pk, g, "up1.conv.", cu1, dd1)
+    dcat1 = _block_bwd(p, pk, g, gw, "up1.conv.", cu1, dd1)
     b1 = cu1.x0.shape[1]
     dd2 = ops.convT2x2_bwd(d2, p["up1.up.weight"], dcat1[:, :b1], g["up1.up.weight"], g["up1.up.bias"])
-    dcat2 = _block_bwd(p, pk, g, "up2.conv.", cu2, dd2)
+    dcat2 = _block_bwd(p, pk, g, gw, "up2.conv.", cu2, dd2)
     b2 = cu2.x0.shape[1]
     dd3 = ops.convT2x2_bwd(d3, p["up2.up.weight"], dcat2[:, :b2], g["up2.up.weight"], g["up2.up.bias"])
-    dcat3 = _block_bwd(p, pk, g, "up3.conv.", cu3, dd3)
+    dcat3 = _block_bwd(p, pk, g, gw, "up3.conv.", cu3, dd3)
     b3 = cu3.x0.shape[1]
     dbott = ops.convT2x2_bwd(bott, p["up3.up.weight"], dcat3[:, :b3], g["up3.up.weight"], g["up3.up.bias"])
 
@@ -203,20 +284,20 @@ def backward(p: Params, pk, g: Params, sv: Saved, dpred: Tensor, need_dx: bool =
         if t > 0:
             dhrec = ops.conv3x3(gx[:, t], pk["lstm.h/d"], ch)
     dA = gx.view(B * T, 4 * ch, h8, w8)            # now holds d(pre-activations) for every (b, t)
-    gw = _zeros(4 * ch, 9, cx + ch, device=dpred.device)
-    ops.wgrad3x3(sv.s4, dA, gw, c_off=0)
+    gl = gw["convlstm.cell.conv.weight"]
+    ops.wgrad3x3(sv.s4, dA, gl, c_off=0)
     if T > 1:
-        ops.wgrad3x3(hprev.view(B * T, ch, h8, w8), dA, gw, c_off=cx)   # hprev[:, 0] == 0 contributes nothing
-    _unpack_into(gw, g["convlstm.cell.conv.weight"])
+        ops.wgrad3x3(hprev.view(B * T, ch, h8, w8), dA, gl, c_off=cx)   # hprev[:, 0] == 0 contributes nothing
     ops.channel_sum(dA, g["convlstm.cell.conv.bias"])
     ds4 = ops.conv3x3(dA, pk["lstm.x/d"], cx)
 
     # ---- encoder ---------------------------------------------------------------------------------------
-    dp3 = _block_bwd(p, pk, g, "enc4.conv.", c4, ds4)
+    dp3 = _block_bwd(p, pk, g, gw, "enc4.conv.", c4, ds4)
     ds3 = ops.maxpool2_bwd(c3.out, dp3, dcat3[:, b3:], t=T)
-    dp2 = _block_bwd(p, pk, g, "enc3.conv.", c3, ds3)
+    dp2 = _block_bwd(p, pk, g, gw, "enc3.conv.", c3, ds3)
     ds2 = ops.maxpool2_bwd(c2.out, dp2, dcat2[:, b2:], t=T)
-    dp1 = _block_bwd(p, pk, g, "enc2.conv.", c2, ds2)
+    dp1 = _block_bwd(p, pk, g, gw, "enc2.conv.", c2, ds2)
     ds1 = ops.maxpool2_bwd(c1.out, dp1, dcat1[:, b1:], t=T)
-    dx = _block_bwd(p, pk, g, "enc1.", c1, ds1, need_dx=need_dx)
+    dx = _block_bwd(p, pk, g, gw, "enc1.", c1, ds1, need_dx=need_dx)
+    plan.unpack()
     return dx.view(sv.x_shape) if dx is not None else None

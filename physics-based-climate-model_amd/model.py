@@ -64,7 +64,7 @@ class _HotPathFunction(torch.autograd.Function):
         # (grad mode is always off inside Function.forward: decide from what autograd says it will ask for)
         need_x = bool(ctx.needs_input_grad[1])
         save = any(ctx.needs_input_grad)
-        pk = engine.pack_weights(p, need_input_grad=need_x)
+        pk = engine.get_plan(p, None, need_x).pack()
         pred, sv = engine.forward(p, pk, x_seq, save=save)
         ctx.module, ctx.sv, ctx.pk, ctx.p, ctx.need_x, ctx.names = module, sv, pk, p, need_x, names
         return pred

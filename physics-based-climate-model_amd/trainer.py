@@ -42,7 +42,7 @@ class HotPathTrainer:
         p = self.model._param_dict()
         g = self.model._views(self.grad)
         check(lib.cm_zero(self.grad.data_ptr(), self.nt * 4, torch.cuda.current_stream().cuda_stream), "zero")
-        pk = engine.pack_weights(p)
+        pk = engine.get_plan(p, None, False).pack()
         pred, sv = engine.forward(p, pk, x, save=True)
         check(lib.cm_mse_loss(pred.data_ptr(), y.data_ptr(), self.loss.data_ptr(), pred.data_ptr(), pred.numel(),
                               torch.cuda.current_stream().cuda_stream), "mse")       # dpred overwrites pred in place
