@@ -21,7 +21,7 @@
 
 namespace {
 
-constexpr int KCH_PACK = 8;   // == KCH below (K-chunk of the conv kernel)
+constexpr int KCH_PACK = 16;  // packed K rows are padded to a multiple of the largest K-chunk any tile configuration uses
 
 struct Conv3Args {
   const float* in0;
@@ -309,23 +309,29 @@ __global__ void pack_batch_kernel(const long long* __restrict__ descs, int ndesc
 }
 
 struct TileCfg {
-  int th, tw, s, waves, npt, wm;
+  int th, tw, s, waves, npt, wm, kc;
 };
-constexpr int KCH = 8;
+constexpr int KCH = KCH_PACK;
 constexpr TileCfg kCfgs[] = {
-    {8, 24, 1, 3, 2, 1},   // 0: 192 px x 32 co
-    {8, 24, 1, 3, 2, 2},   // 1: 192 px x 64 co
-    {16, 24, 1, 4, 3, 1},  // 2: 384 px x 32 co
-    {8, 36, 1, 3, 3, 2},   // 3: 288 px x 64 co
-    {8, 12, 1, 3, 1, 2},   // 4:  96 px x 64 co
-    {4, 18, 4, 3, 3, 2},   // 5: 4 samples x 72 px x 64 co
-    {12, 18, 1, 4, 2, 2},  // 6: 216 px (7 of 8 tiles) x 64 co
-    {6, 9, 2, 4, 1, 1},    // 7: 2 samples x 54 px x 32 co
-    {6, 9, 2, 4, 1, 2},    // 8: 2 samples x 54 px x 64 co
-    {6, 9, 4, 4, 2, 2},    // 9: 4 samples x 54 px x 64 co
-    {8, 16, 1, 4, 1, 1},   // 10: generic 128 px x 32 co
-    {8, 16, 1, 4, 1, 2},   // 11: generic 128 px x 64 co
-    {12, 18, 1, 4, 2, 1},  // 12: 216 px x 32 co
+    {8, 24, 1, 3, 2, 1, 8},   // 0: 192 px x 32 co
+    {8, 24, 1, 3, 2, 2, 8},   // 1: 192 px x 64 co
+    {16, 24, 1, 4, 3, 1, 8},  // 2: 384 px x 32 co
+    {8, 36, 1, 3, 3, 2, 8},   // 3: 288 px x 64 co
+    {8, 12, 1, 3, 1, 2, 8},   // 4:  96 px x 64 co
+    {4, 18, 4, 3, 3, 2, 8},   // 5: 4 samples x 72 px x 64 co
+    {12, 18, 1, 4, 2, 2, 8},  // 6: 216 px (7 of 8 tiles) x 64 co
+    {6, 9, 2, 4, 1, 1, 8},    // 7: 2 samples x 54 px x 32 co
+    {6, 9, 2, 4, 1, 2, 8},    // 8: 2 samples x 54 px x 64 co
+    {6, 9, 4, 4, 2, 2, 8},    // 9: 4 samples x 54 px x 64 co
+    {8, 16, 1, 4, 1, 1, 8},   // 10: generic 128 px x 32 co
+    {8, 16, 1, 4, 1, 2, 8},   // 11: generic 128 px x 64 co
+    {12, 18, 1, 4, 2, 1, 8},  // 12: 216 px x 32 co
+    {6, 9, 2, 4, 1, 1, 16},   // 13: as 7, 16-channel K chunks
+    {8, 16, 1, 4, 1, 1, 16},  // 14: as 10, 16-channel K chunks
+    {12, 18, 1, 4, 2, 1, 16}, // 15: as 12, 16-channel K chunks
+    {6, 9, 2, 4, 1, 2, 16},   // 16: as 8, 16-channel K chunks
+    {6, 9, 4, 4, 2, 1, 8},    // 17: 4 samples x 54 px x 32 co
+    {6, 9, 4, 4, 2, 1, 16},   // 18: same, 16-channel K chunks
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -335,15 +341,20 @@ int launch_cfg(const Conv3Args& a0, hipStream_t st) {
   Conv3Args a = a0;
   a.tiles_x = cdiv(a.W, c.tw);
   a.tiles_y = cdiv(a.H, c.th);
-  if (a.ksplit > a.nchunks) a.ksplit = a.nchunks;
-  if (a.ksplit < 1) a.ksplit = 1;
+  {
+    const int nch = (a.C0 + a.C1 + c.kc - 1) / c.kc;
+    if (a.ksplit > nch) a.ksplit = nch;
+    if (a.ksplit < 1) a.ksplit = 1;
+  }
   if (a.ksplit > 1) {
     const long long per = (long long)a.Cout * a.H * a.W;
     long long zb = ((long long)a.N * per + 255) / 256;
     zero_out_kernel<<<(int)(zb > 2048 ? 2048 : zb), 256, 0, st>>>(a.out, a.sto, a.N, per);
   }
   dim3 grid(a.tiles_x * a.tiles_y * cdiv(a.N, c.s), cdiv(a.Cout, 32 * c.wm), a.ksplit);
-  conv3x3_mfma_kernel<c.th, c.tw, c.s, c.waves, c.npt, c.wm, KCH, DUAL><<<grid, c.waves * 64, 0, st>>>(a);
+  a.nchunks = (a.C0 + a.C1 + c.kc - 1) / c.kc;
+  if (a.C1 > 0 && (a.C0 % c.kc) != 0) return -22;  // a K-chunk must not straddle the two inputs
+  conv3x3_mfma_kernel<c.th, c.tw, c.s, c.waves, c.npt, c.wm, c.kc, DUAL><<<grid, c.waves * 64, 0, st>>>(a);
   CM_CHECK_LAUNCH();
   return 0;
 }
@@ -364,6 +375,12 @@ int dispatch(int cfg, const Conv3Args& a, hipStream_t st) {
     case 10: return launch_cfg<10, DUAL>(a, st);
     case 11: return launch_cfg<11, DUAL>(a, st);
     case 12: return launch_cfg<12, DUAL>(a, st);
+    case 13: return launch_cfg<13, DUAL>(a, st);
+    case 14: return launch_cfg<14, DUAL>(a, st);
+    case 15: return launch_cfg<15, DUAL>(a, st);
+    case 16: return launch_cfg<16, DUAL>(a, st);
+    case 17: return launch_cfg<17, DUAL>(a, st);
+    case 18: return launch_cfg<18, DUAL>(a, st);
     default: return -22;
   }
 }
@@ -429,14 +446,14 @@ int cm_conv3x3(const float* in0, long long st0, int c0, const float* in1, long l
                const float* bias, const float* resid, long long st_resid, float* out, long long st_out, int n, int h,
                int w, int cout, int config, cm_stream stream) {
   if (n <= 0 || h <= 0 || w <= 0 || cout <= 0 || c0 <= 0 || c1 < 0) return -22;
-  if (c1 > 0 && (c0 % KCH) != 0) return -22;  // a K-chunk must not straddle the two inputs
+  if (c1 > 0 && (c0 % 8) != 0) return -22;  // a K-chunk must not straddle the two inputs
   if (resid && st_resid != st_out) return -22;
   Conv3Args a;
   a.in0 = in0; a.in1 = in1; a.st0 = st0; a.st1 = st1; a.C0 = c0; a.C1 = c1;
   a.wp = wp; a.bias = bias; a.resid = resid; a.str = st_resid; a.out = out; a.sto = st_out;
   a.N = n; a.H = h; a.W = w; a.Cout = cout;
   a.CoutP = ((cout + 31) / 32) * 32;
-  a.nchunks = (c0 + c1 + KCH - 1) / KCH;
+  a.nchunks = 0;   // set per tile configuration
   a.tiles_x = a.tiles_y = 0;
   if (config < 0) config = cm_conv3x3_pick_config(n, h, w, cout);
   a.ksplit = config >> 8;                    // bits 8.. = K split over blockIdx.z (0/1 = none)

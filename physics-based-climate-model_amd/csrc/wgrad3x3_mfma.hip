@@ -226,6 +226,222 @@ __global__ __launch_bounds__(192 * MO * KS, 2) void wgrad3x3_mfma_kernel(WgArgs 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Double-buffered variant: one 12-wave workgroup per CU.  Two LDS stages let the LDS stores of unit u+1 and the global
+// loads of unit u+2 overlap the MFMA phase of unit u with ONE barrier per unit; the KS wave groups (which split a
+// unit's pixel pairs) are summed through LDS at the end so each output element costs one atomic per workgroup.
+template <int TH, int TW, int S, int MO, int KS, bool DUAL>
+__global__ __launch_bounds__(192 * MO * KS) void wgrad3x3_db_kernel(WgArgs a) {
+  constexpr int THREADS = 192 * MO * KS;
+  constexpr int PITCH = TW + 2;
+  constexpr int SS = (TH + 2) * PITCH;
+  constexpr int CS0 = S * SS;
+  constexpr int CS = (CS0 % 2 == 0) ? CS0 + 1 : CS0;
+  constexpr int PIX = S * TH * TW;
+  constexpr int PP = (PIX % 2 == 0) ? PIX + 1 : PIX;
+  constexpr int RSTEP = (TW % 2) ? 2 : 1;
+  constexpr int NPAIR = RSTEP * TW / 2;
+  constexpr int ITERS_PER_SAMPLE = TH / RSTEP;
+  constexpr int ITERS = S * ITERS_PER_SAMPLE;
+  constexpr int XSZ = 32 * CS, DSZ = 32 * MO * PP, STAGE = XSZ + DSZ;
+  static_assert(TH % RSTEP == 0, "odd tile widths need an even tile height");
+  static_assert((KS & (KS - 1)) == 0, "KS must be a power of two");
+  // (the launcher sizes the dynamic LDS as max(2 * STAGE, (KS/2) * MO * 3 * 3072) floats for the final reduction)
+
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int dyrow = wave % 3, grp = wave / 3;
+  const int mo = grp % MO, ks = grp / MO;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int HW = a.H * a.W;
+  const int co0 = blockIdx.y * 32 * MO;
+  const int ci0 = blockIdx.z * 32;
+  const int Cin = a.C0 + a.C1;
+
+  const float* const a_x0 = a.x0;
+  const float* const a_x1 = a.x1;
+  const float* const a_dy = a.dy;
+  const long long sx0 = a.sx0, sx1 = a.sx1, sdy = a.sdy;
+  const int C0 = a.C0, N = a.N, H = a.H, W = a.W, Cout = a.Cout;
+  const int tiles_x = a.tiles_x, tiles_y = a.tiles_y;
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+
+  const int bN = l31 * CS + dyrow * PITCH + half;
+  const int bW = l31 * CS + dyrow * PITCH + half * (PITCH - TW + 1);
+  const int aB = XSZ + (mo * 32 + l31) * PP + half;
+
+  const int u_begin = blockIdx.x * a.units_per_block;
+  const int u_end = min(a.units, u_begin + a.units_per_block);
+  if (u_begin >= u_end) return;
+
+  constexpr int XTPR = (PITCH + 3) / 4;
+  constexpr int XROWS = 32 * S * (TH + 2);
+  constexpr int XITEMS = XROWS * XTPR;
+  constexpr int NIX = (XITEMS + THREADS - 1) / THREADS;
+  constexpr int DTPR = (TW + 3) / 4;
+  constexpr int DROWS = 32 * MO * S * TH;
+  constexpr int DITEMS = DROWS * DTPR;
+  constexpr int NID = (DITEMS + THREADS - 1) / THREADS;
+  float xr[NIX][4], dr[NID][4];
+
+  auto load_unit = [&](int u) {
+    int t = u;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int g = t / tiles_y;
+    const int x0 = tx * TW, y0 = ty * TH, n0 = g * S;
+    const float* xb0 = a_x0 + (long long)n0 * sx0;
+    const float* xb1 = DUAL ? a_x1 + (long long)n0 * sx1 : a_x0;
+    const float* db = a_dy + (long long)n0 * sdy + (long long)co0 * HW;
+    const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb0), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb1), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(db), 0, 0x7FFFFFFF, 0x00020000);
+    int tq = tid;
+    asm volatile("" : "+v"(tq));
+#pragma unroll
+    for (int it = 0; it < NIX; ++it) {
+      const int item = tq + it * THREADS;
+      const int row = item / XTPR, col0 = (item % XTPR) * 4;
+      const int c = row / (S * (TH + 2)), rem = row % (S * (TH + 2));
+      const int s = rem / (TH + 2), r = rem % (TH + 2);
+      const int gy = y0 - 1 + r, gx0 = x0 - 1 + col0;
+      const int ch = ci0 + c;
+      const bool rowok = (item < XITEMS) && ch < Cin && (n0 + s < N) && gy >= 0 && gy < H;
+      const bool in1 = DUAL && ch >= C0;
+      const int off0 = (s * (int)sx0 + ch * HW + gy * W + gx0) * 4;
+      const int off1 = (s * (int)sx1 + (ch - C0) * HW + gy * W + gx0) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool ok = rowok && (col0 + j < PITCH) && (gx0 + j >= 0) && (gx0 + j < W);
+        int v = __builtin_amdgcn_raw_buffer_load_b32(rx0, (ok && !in1) ? off0 + 4 * j : -1, 0, 0);
+        if (DUAL) v |= __builtin_amdgcn_raw_buffer_load_b32(rx1, (ok && in1) ? off1 + 4 * j : -1, 0, 0);
+        xr[it][j] = __int_as_float(v);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NID; ++it) {
+      const int item = tq + it * THREADS;
+      const int row = item / DTPR, col0 = (item % DTPR) * 4;
+      const int o = row / (S * TH), rem = row % (S * TH);
+      const int s = rem / TH, r = rem % TH;
+      const int gy = y0 + r, gx0 = x0 + col0;
+      const bool rowok = (item < DITEMS) && co0 + o < Cout && (n0 + s < N) && gy < H;
+      const int off = (s * (int)sdy + o * HW + gy * W + gx0) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool ok = rowok && (col0 + j < TW) && (gx0 + j < W);
+        dr[it][j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, ok ? off + 4 * j : -1, 0, 0));
+      }
+    }
+  };
+  auto store_unit = [&](float* stage) {
+    int ts = tid;
+    asm volatile("" : "+v"(ts));
+#pragma unroll
+    for (int it = 0; it < NIX; ++it) {
+      const int item = ts + it * THREADS;
+      const int row = item / XTPR, col0 = (item % XTPR) * 4;
+      const int c = row / (S * (TH + 2)), rem = row % (S * (TH + 2));
+      const int base = c * CS + rem * PITCH + col0;
+      if (item < XITEMS) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (col0 + j < PITCH) stage[base + j] = xr[it][j];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NID; ++it) {
+      const int item = ts + it * THREADS;
+      const int row = item / DTPR, col0 = (item % DTPR) * 4;
+      const int o = row / (S * TH), rem = row % (S * TH);
+      const int base = XSZ + o * PP + rem * TW + col0;
+      if (item < DITEMS) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (col0 + j < TW) stage[base + j] = dr[it][j];
+      }
+    }
+  };
+
+  load_unit(u_begin);
+  store_unit(lds);
+  if (u_begin + 1 < u_end) load_unit(u_begin + 1);
+  __syncthreads();
+  for (int u = u_begin; u < u_end; ++u) {
+    float* cur = lds + ((u - u_begin) & 1) * STAGE;
+    float* nxt = lds + (((u - u_begin) & 1) ^ 1) * STAGE;
+    if (u + 1 < u_end) store_unit(nxt);        // nxt was last read in the MFMA phase of unit u-1 (before the barrier)
+    if (u + 2 < u_end) load_unit(u + 2);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+    for (int it = ks; it < ITERS; it += KS) {
+      const int sidx = it / ITERS_PER_SAMPLE, r = (it % ITERS_PER_SAMPLE) * RSTEP;
+      const int xo = sidx * SS + r * PITCH;
+      const int dofs = sidx * (TH * TW) + r * TW;
+      const float* dlp = cur + aB + dofs;
+      const float* xn = cur + bN + xo;
+      const float* xw = cur + bW + xo;
+#pragma unroll
+      for (int j = 0; j < NPAIR; ++j) {
+        const int q0 = 2 * j;
+        const int f = (q0 / TW) * PITCH + (q0 % TW);
+        const bool wrap = (q0 % TW) == TW - 1;
+        const float av = dlp[q0];
+        float bv[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) bv[d] = wrap ? xw[f + d] : xn[f + d];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) acc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[d], acc[d], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- sum the KS wave groups through LDS (tree), then one atomic per output element and workgroup ----
+  if (KS > 1) {
+    const int slot = mo * 3 + dyrow;                       // wave position inside its group
+#pragma unroll
+    for (int stride = KS / 2; stride >= 1; stride >>= 1) {
+      if (ks >= stride && ks < 2 * stride) {
+        float* dst = lds + ((ks - stride) * (MO * 3) + slot) * 3072 + lane;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[(d * 16 + r) * 64] = acc[d][r];
+      }
+      __syncthreads();
+      if (ks < stride) {
+        const float* src = lds + (ks * (MO * 3) + slot) * 3072 + lane;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[d][r] += src[(d * 16 + r) * 64];
+      }
+      __syncthreads();
+    }
+  }
+  const int ch = ci0 + l31;
+  if (ks == 0 && ch < Cin) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + mo * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co < Cout) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+          unsafeAtomicAdd(a.g + ((long long)co * 9 + dyrow * 3 + d) * a.Ctot + a.c_off + ch, acc[d][r]);
+      }
+    }
+  }
+}
+
 // G[o][tap][c] -> dW[o][c][tap]   (optionally scaled)
 __global__ void wgrad_unpack_kernel(const float* __restrict__ g, float* __restrict__ dw, int cout, int ctot,
                                     float scale) {
@@ -260,21 +476,28 @@ __global__ void wgrad_unpack_batch_kernel(const long long* __restrict__ descs, i
 }
 
 struct WgCfg {
-  int th, tw, s, mo, ks;
+  int th, tw, s, mo, ks, db;   // db = 1: double-buffered 12-wave kernel
 };
 constexpr WgCfg kWg[] = {
-    {8, 24, 1, 1, 2},   // 0: 192 px, 32 couts, pixel pairs split over 2 wave groups
-    {8, 12, 1, 2, 1},   // 1:  96 px, 64 couts
-    {4, 18, 1, 2, 1},   // 2:  72 px, 64 couts
-    {6, 18, 1, 2, 1},   // 3: 108 px, 64 couts
-    {6, 9, 2, 2, 1},    // 4: 2 samples x 54 px, 64 couts
-    {8, 16, 1, 1, 2},   // 5: generic 128 px, 32 couts
-    {4, 36, 1, 1, 2},   // 6: 144 px, 32 couts
-    {8, 16, 1, 2, 1},   // 7: generic 128 px, 64 couts
-    {6, 9, 4, 2, 2},    // 8: 4 samples x 54 px, 64 couts, 12 waves
-    {12, 18, 1, 2, 2},  // 9: 216 px, 64 couts, 12 waves
-    {8, 24, 1, 1, 1},   // 10: 192 px, 32 couts, 3 waves
-    {8, 16, 1, 1, 1},   // 11: 128 px, 32 couts, 3 waves
+    {8, 24, 1, 1, 2, 0},   // 0: 192 px, 32 couts, pixel pairs split over 2 wave groups
+    {8, 12, 1, 2, 1, 0},   // 1:  96 px, 64 couts
+    {4, 18, 1, 2, 1, 0},   // 2:  72 px, 64 couts
+    {6, 18, 1, 2, 1, 0},   // 3: 108 px, 64 couts
+    {6, 9, 2, 2, 1, 0},    // 4: 2 samples x 54 px, 64 couts
+    {8, 16, 1, 1, 2, 0},   // 5: generic 128 px, 32 couts
+    {4, 36, 1, 1, 2, 0},   // 6: 144 px, 32 couts
+    {8, 16, 1, 2, 1, 0},   // 7: generic 128 px, 64 couts
+    {6, 9, 4, 2, 2, 0},    // 8: 4 samples x 54 px, 64 couts, 12 waves
+    {12, 18, 1, 2, 2, 0},  // 9: 216 px, 64 couts, 12 waves
+    {8, 24, 1, 1, 1, 0},   // 10: 192 px, 32 couts, 3 waves
+    {8, 16, 1, 1, 1, 0},   // 11: 128 px, 32 couts, 3 waves
+    {6, 9, 2, 2, 2, 1},    // 12: db, 2 samples x 54 px, 64 couts
+    {6, 18, 1, 2, 2, 1},   // 13: db, 108 px, 64 couts
+    {8, 12, 1, 2, 2, 1},   // 14: db, 96 px, 64 couts
+    {8, 16, 1, 1, 4, 1},   // 15: db, 128 px, 32 couts
+    {8, 24, 1, 1, 4, 1},   // 16: db, 192 px, 32 couts
+    {4, 36, 1, 1, 4, 1},   // 17: db, 144 px, 32 couts
+    {6, 9, 2, 1, 4, 1},    // 18: db, 2 samples x 54 px, 32 couts
 };
 constexpr int kNumWg = sizeof(kWg) / sizeof(kWg[0]);
 
@@ -288,12 +511,24 @@ int launch_wg(const WgArgs& a0, hipStream_t st) {
   const int gy = cdiv(a.Cout, 32 * c.mo), gz = cdiv(a.C0 + a.C1, 32);
   // Size the grid to the number of resident workgroup slots (256 CUs x occupancy): with `rounds4`/4 rounds of
   // equally loaded workgroups there is no partially filled last round.  a0.units_per_block carries rounds4 (0 = 4).
+  constexpr int PITCHc = c.tw + 2, CS0c = c.s * (c.th + 2) * PITCHc, CSc = (CS0c % 2 == 0) ? CS0c + 1 : CS0c;
+  constexpr int PIXc = c.s * c.th * c.tw, PPc = (PIXc % 2 == 0) ? PIXc + 1 : PIXc;
+  constexpr size_t db_stage = (size_t)2 * (32 * CSc + 32 * c.mo * PPc), db_red = (size_t)(c.ks / 2) * c.mo * 3 * 3072;
+  constexpr size_t db_lds = (db_stage > db_red ? db_stage : db_red) * sizeof(float);
   static int occ = 0;
   if (occ == 0) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, wgrad3x3_mfma_kernel<c.th, c.tw, c.s, c.mo, c.ks, DUAL>,
-                                                     192 * c.mo * c.ks, 0) != hipSuccess || nb < 1)
+    if (c.db) {
+      if (hipFuncSetAttribute((const void*)wgrad3x3_db_kernel<c.th, c.tw, c.s, c.mo, c.ks, DUAL>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)db_lds) != hipSuccess)
+        return -22;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, wgrad3x3_db_kernel<c.th, c.tw, c.s, c.mo, c.ks, DUAL>,
+                                                       192 * c.mo * c.ks, db_lds) != hipSuccess || nb < 1)
+        nb = 1;
+    } else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, wgrad3x3_mfma_kernel<c.th, c.tw, c.s, c.mo, c.ks, DUAL>,
+                                                            192 * c.mo * c.ks, 0) != hipSuccess || nb < 1) {
       nb = 1;
+    }
     occ = nb;
   }
   const int rounds4 = a0.units_per_block > 0 ? a0.units_per_block : 4;
@@ -304,7 +539,10 @@ int launch_wg(const WgArgs& a0, hipStream_t st) {
   if (upb < 1) upb = 1;
   a.units_per_block = upb;
   dim3 grid(cdiv(a.units, upb), gy, gz);
-  wgrad3x3_mfma_kernel<c.th, c.tw, c.s, c.mo, c.ks, DUAL><<<grid, 192 * c.mo * c.ks, 0, st>>>(a);
+  if (c.db)
+    wgrad3x3_db_kernel<c.th, c.tw, c.s, c.mo, c.ks, DUAL><<<grid, 192 * c.mo * c.ks, db_lds, st>>>(a);
+  else
+    wgrad3x3_mfma_kernel<c.th, c.tw, c.s, c.mo, c.ks, DUAL><<<grid, 192 * c.mo * c.ks, 0, st>>>(a);
   CM_CHECK_LAUNCH();
   return 0;
 }
@@ -324,6 +562,13 @@ int dispatch_wg(int cfg, const WgArgs& a, hipStream_t st) {
     case 9: return launch_wg<9, DUAL>(a, st);
     case 10: return launch_wg<10, DUAL>(a, st);
     case 11: return launch_wg<11, DUAL>(a, st);
+    case 12: return launch_wg<12, DUAL>(a, st);
+    case 13: return launch_wg<13, DUAL>(a, st);
+    case 14: return launch_wg<14, DUAL>(a, st);
+    case 15: return launch_wg<15, DUAL>(a, st);
+    case 16: return launch_wg<16, DUAL>(a, st);
+    case 17: return launch_wg<17, DUAL>(a, st);
+    case 18: return launch_wg<18, DUAL>(a, st);
     default: return -22;
   }
 }

@@ -38,7 +38,8 @@ def _pick(key, candidates, launch, fallback):
         return fallback
     best, best_t = fallback, float("inf")
     for cfg in (range(candidates) if isinstance(candidates, int) else candidates):
-        launch(cfg)
+        if launch(cfg) != 0:          # configuration not applicable to this call (argument error): skip it
+            continue
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -87,8 +88,8 @@ def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1):
         def launch(cfg, _scratch=[None]):
             if _scratch[0] is None:
                 _scratch[0] = torch.empty(n, cout, h, w, device=x0.device, dtype=torch.float32)
-            check(lib.cm_conv3x3(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(wp), _p(bias), None, 0,
-                                 _p(_scratch[0]), _scratch[0].stride(0), n, h, w, cout, cfg, _stream()), "conv3x3 tune")
+            return lib.cm_conv3x3(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(wp), _p(bias), None, 0,
+                                  _p(_scratch[0]), _scratch[0].stride(0), n, h, w, cout, cfg, _stream())
         nchunks = (c0 + c1 + 7) // 8
         splits = [1] + [k for k in (2, 4, 8) if nchunks >= 4 * k and not (resid is not None and resid.data_ptr() == out.data_ptr())]
         cands = [c + ((k if k > 1 else 0) << 8) for c in range(lib.cm_conv3x3_num_configs()) for k in splits]
@@ -109,8 +110,8 @@ def wgrad3x3(x0, dy, g, c_off=0, x1=None, config=-1):
         def launch(cfg, _scratch=[None]):
             if _scratch[0] is None:
                 _scratch[0] = torch.empty_like(g)
-            check(lib.cm_wgrad3x3(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(dy), dy.stride(0), _p(_scratch[0]),
-                                  ctot, c_off, n, h, w, cout, cfg, _stream()), "wgrad3x3 tune")
+            return lib.cm_wgrad3x3(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(dy), dy.stride(0), _p(_scratch[0]),
+                                   ctot, c_off, n, h, w, cout, cfg, _stream())
         cands = [c + (u << 8) for c in range(lib.cm_wgrad3x3_num_configs()) for u in (2, 3, 4, 6, 8)]
         config = _pick(("wgrad3x3", n, h, w, c0, c1, cout), cands, launch, -1)
     check(lib.cm_wgrad3x3(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(dy),

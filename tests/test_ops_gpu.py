@@ -41,7 +41,7 @@ def test_conv_identity_asymmetric(ops):
     for i in range(c):
         wt[i, i, 1, 1] = 1.0
     wp = ops.pack_conv3x3(dev(wt))
-    for cfg in range(13):
+    for cfg in range(19):
         y = ops.conv3x3(dev(x), wp, c, config=cfg)
         assert torch.equal(y.cpu(), x), f"config {cfg}"
     # permutation of channels + a shifted tap
@@ -76,7 +76,9 @@ def test_conv3x3_all_configs(ops, case):
     xin = x0 if x1 is None else torch.cat([x0, x1], 1)
     ref = F.conv2d(xin.double(), wt.double(), b.double(), padding=1) + r.double()
     wp = ops.pack_conv3x3(dev(wt))
-    for cfg in list(range(13)) + [-1]:
+    for cfg in list(range(19)) + [-1]:
+        if cfg >= 13 and cfg != 17 and c1 and c0 % 16:
+            continue            # 16-channel K chunks cannot straddle the two inputs (the launcher refuses: -22)
         y = ops.conv3x3(dev(x0), wp, cout, x1=None if x1 is None else dev(x1), bias=dev(b), resid=dev(r), config=cfg)
         assert rel_l2(y, ref) < TOL, f"config {cfg}: {rel_l2(y, ref)}"
 
@@ -128,7 +130,7 @@ def test_wgrad3x3_all_configs(ops, case):
     wt = torch.zeros(cout, c0 + c1, 3, 3, dtype=torch.float64, requires_grad=True)
     F.conv2d(xin.double(), wt, padding=1).backward(dy.double())
     ctot = c0 + c1 + 4
-    for cfg in list(range(12)) + [-1]:
+    for cfg in list(range(19)) + [-1]:
         g = torch.zeros(cout, 9, ctot, device="cuda")
         ops.wgrad3x3(dev(x0), dev(dy), g, c_off=4, x1=None if x1 is None else dev(x1), config=cfg)
         dw = ops.wgrad3x3_unpack(g)
