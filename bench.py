@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); 'gloo' allows a "
+                    "multi-process rehearsal on a single GPU")
     args = ap.parse_args()
 
     from climate_amd import ddp
@@ -83,11 +85,12 @@ def main():
     from climate_amd.trainer import HotPathTrainer
     import torch.distributed as dist
 
-    rank, local, world = ddp.init_from_env()
+    rank, local, world = ddp.init_from_env(backend=args.backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    local = local % torch.cuda.device_count()      # (gloo rehearsal: several ranks may share one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -122,7 +125,7 @@ def main():
 
     # ---- roofline pass: same workload, eager launches, HIP events around every launcher --------------------------
     roof, kernels = None, {}
-    if rank == 0:
+    if rank == 0 and args.profile_steps > 0:
         tr_e = tr
         tr_e.use_graph = False
         with KernelTimer() as kt:

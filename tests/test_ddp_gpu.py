@@ -1,0 +1,73 @@
+"""Two ranks (gloo rehearsal of the RCCL path, both on cuda:0) must reproduce the single-process step on the
+concatenated batch: shard -> local fwd/bwd -> SUM all-reduce of the flat gradient -> Adam with grad_scale 1/world."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import oracle
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+CFG = dict(in_ch=5, out_ch=2, base=8, T=3, B=4, H=16, W=24)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _batch():
+    g = torch.Generator("cpu").manual_seed(11)
+    x = torch.randn(CFG["B"], CFG["T"], CFG["in_ch"], CFG["H"], CFG["W"], generator=g)
+    y = torch.randn(CFG["B"], CFG["out_ch"], CFG["H"], CFG["W"], generator=g)
+    return x, y
+
+
+def _model():
+    from climate_amd.model import AttUNetConvLSTM
+    m = AttUNetConvLSTM(CFG["in_ch"], CFG["out_ch"], CFG["base"], CFG["T"])
+    m.load_state_dict(oracle.closed_form_params(CFG["in_ch"], CFG["out_ch"], CFG["base"]))
+    return m.cuda()
+
+
+def _worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    from climate_amd import ddp
+    from climate_amd.trainer import HotPathTrainer
+    ddp.init_from_env(backend="gloo")
+    torch.cuda.set_device(0)
+    m = _model()
+    if rank == 1:                        # ranks start different; the trainer's broadcast must repair it
+        with torch.no_grad():
+            for p in m.parameters():
+                p.add_(0.123)
+    tr = HotPathTrainer(m, lr=5e-4, use_graph=(rank == 0))   # one rank replays a hipGraph, the other runs eagerly
+    x, y = _batch()
+    sl = ddp.shard_batch(CFG["B"], rank, world)
+    for _ in range(2):
+        tr.step(x[sl].cuda(), y[sl].cuda())
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save({k: v.cpu() for k, v in m.state_dict().items()}, out_path)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_match_single_process(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from climate_amd.trainer import HotPathTrainer
+    out_path = str(tmp_path / "rank0.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    got = torch.load(out_path, weights_only=True)
+    m = _model()
+    tr = HotPathTrainer(m, lr=5e-4, use_graph=False, distributed=False)
+    x, y = _batch()
+    for _ in range(2):
+        tr.step(x.cuda(), y.cuda())
+    want = m.state_dict()
+    for k in want:
+        assert rel_l2(got[k], want[k]) < 2e-6, k
