@@ -38,9 +38,30 @@ def train_flops_per_sample(b, T, H, W, cin=5, cout=2):
     return 3 * (T * enc + T * lstm + dec + head)
 
 
+def usable_cores():
+    """CPU cores this process may really use: affinity mask capped by the cgroup CPU quota (containers)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_baseline(cfg, steps=5):
     """Full training step of the CPU oracle (a port of the reference's path) on this box's host cores."""
     import oracle
+    torch.set_num_threads(usable_cores())
     B, T, C, H, W, base = cfg["B"], cfg["T"], cfg["C"], cfg["H"], cfg["W"], cfg["base"]
     torch.manual_seed(42)
     P = {k: v.clone().requires_grad_() for k, v in oracle.closed_form_params(C, 2, base).items()}

@@ -2,70 +2,16 @@
 //
 // Reference: nn.ConvTranspose2d(c_in, c_out, 2, stride=2) (src/unet.py:63,67); weight layout [C_in][C_out][2][2].
 //   y[n,o,2y+dy,2x+dx] = b[o] + sum_c x[n,c,y,x] * W[c,o,dy,dx]
-// Non-overlapping: each output pixel has exactly one source pixel, so this is four 1x1 GEMMs with K = C_in.  It is
-// <1 % of the step's flops and HBM-light; these kernels keep the weight slice wave-uniform (scalar loads) and
-// stream activations coalesced along pixels.
+// Non-overlapping: each output pixel has exactly one source pixel, so this is four 1x1 GEMMs with K = C_in.  The forward
+// lives in conv_transpose_mfma.hip (MFMA); this file holds the data gradient (VALU, LDS-staged weights: measured faster
+// than the MFMA form at these small sizes, whose K = 4*C_out loop is latency bound) and the weight gradient.
 #include "common.h"
 #include "../../include/climate_hip.h"
 
 namespace {
 
-constexpr int OT = 8;    // output channels per thread (fwd) / input channels per thread (bwd data)
+constexpr int OT = 8;    // input channels per thread (bwd data)
 constexpr int KCH = 64;  // reduction-channel chunk whose weight slab is staged in LDS
-
-// thread <-> input pixel; blockIdx.y = sample; blockIdx.z = chunk of OT output channels.
-// The weight slab w[c][o0..o0+OT)[4] of a KCH-channel chunk is staged in LDS (broadcast reads); activations stream
-// coalesced along pixels with the channel loop unrolled so several loads are in flight.
-__global__ __launch_bounds__(256) void convT_fwd_kernel(const float* __restrict__ x, long long sx,
-                                                         const float* __restrict__ w, const float* __restrict__ b,
-                                                         float* __restrict__ y, long long sy, int Ci, int Co, int H,
-                                                         int W) {
-  __shared__ __attribute__((aligned(16))) float wsh[KCH][OT * 4];
-  const int HW = H * W, Wo = 2 * W;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n = blockIdx.y, o0 = blockIdx.z * OT;
-  const bool live = p < HW;
-  float acc[OT][4];
-#pragma unroll
-  for (int j = 0; j < OT; ++j) {
-    const float bv = (o0 + j < Co) ? b[o0 + j] : 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) acc[j][k] = bv;
-  }
-  const float* xp = x + (long long)n * sx + (live ? p : 0);
-  for (int c0 = 0; c0 < Ci; c0 += KCH) {
-    const int kc = min(KCH, Ci - c0);
-    __syncthreads();
-    for (int i = threadIdx.x; i < kc * OT * 4; i += blockDim.x) {
-      const int c = i / (OT * 4), r = i % (OT * 4);
-      wsh[c][r] = (o0 + r / 4 < Co) ? w[((long long)(c0 + c) * Co + o0) * 4 + r] : 0.f;
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int c = 0; c < kc; ++c) {
-      const float xv = xp[(long long)(c0 + c) * HW];
-      const float4* wr = reinterpret_cast<const float4*>(&wsh[c][0]);
-#pragma unroll
-      for (int j = 0; j < OT; ++j) {
-        const float4 wv = wr[j];
-        acc[j][0] += xv * wv.x;
-        acc[j][1] += xv * wv.y;
-        acc[j][2] += xv * wv.z;
-        acc[j][3] += xv * wv.w;
-      }
-    }
-  }
-  if (!live) return;
-  const int yy = p / W, xx = p % W;
-#pragma unroll
-  for (int j = 0; j < OT; ++j) {
-    if (o0 + j < Co) {
-      float* yp = y + (long long)n * sy + (long long)(o0 + j) * 4 * HW + (long long)(2 * yy) * Wo + 2 * xx;
-      *reinterpret_cast<float2*>(yp) = make_float2(acc[j][0], acc[j][1]);
-      *reinterpret_cast<float2*>(yp + Wo) = make_float2(acc[j][2], acc[j][3]);
-    }
-  }
-}
 
 // dx[n,c,y,x] = sum_{o,k} dy[n,o,2y+ky,2x+kx] * W[c,o,k];  thread <-> input pixel, OT input channels per thread;
 // weight slab w[c0..c0+OT)[o chunk][4] staged in LDS as [o][OT][4].
@@ -167,16 +113,6 @@ __global__ __launch_bounds__(256) void convT_bwd_weight_kernel(const float* __re
 }  // namespace
 
 extern "C" {
-
-int cm_convT2x2_fwd(const float* x, long long sx, const float* w, const float* b, float* y, long long sy, int n,
-                    int ci, int co, int h, int w_, cm_stream stream) {
-  if (n <= 0 || ci <= 0 || co <= 0 || h <= 0 || w_ <= 0) return -22;
-  const int hw = h * w_, bs = hw >= 256 ? 256 : 64;
-  convT_fwd_kernel<<<dim3(cdiv(hw, bs), n, cdiv(co, OT)), bs, 0, (hipStream_t)stream>>>(x, sx, w, b, y, sy, ci, co, h,
-                                                                                        w_);
-  CM_CHECK_LAUNCH();
-  return 0;
-}
 
 int cm_convT2x2_bwd_data(const float* dy, long long sdy, const float* w, float* dx, long long sdx, int n, int ci,
                          int co, int h, int w_, cm_stream stream) {

@@ -9,6 +9,7 @@
 //
 // All passes are HBM/L2 streaming passes; statistics use a two-pass (mean, then centred sum of squares) scheme in
 // fp32 so they stay within ~1e-7 of torch's CPU result.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/climate_hip.h"
 
@@ -222,6 +223,189 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_kernel(const float* __
   }
 }
 
+// Register-resident variants (float4 path, group small enough): each wave owns whole 64-quad "rows" of channels and keeps
+// them in registers between the reduction pass and the apply pass, so every tensor is read from HBM exactly once.
+//   forward : read x, write y                      (2 passes instead of 3)
+//   backward: read x, upstream; write dx           (3 / 4 passes instead of 6 / 7)
+template <int MAXQ>
+__global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_reg_kernel(const float* __restrict__ x,
+                                                                       const float* __restrict__ gamma,
+                                                                       const float* __restrict__ beta,
+                                                                       float* __restrict__ y, float* __restrict__ stats,
+                                                                       float* __restrict__ pooled, int C, int HW, int G,
+                                                                       float eps) {
+  __shared__ float red[32];
+  __shared__ float psum[64];
+  const int n = blockIdx.x / G, g = blockIdx.x % G;
+  const int cpg = C / G;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = GN_THREADS / 64;
+  const int HWV = HW / 4, RPC = (HWV + 63) / 64, rows = cpg * RPC;
+  const long long base = ((long long)n * C + (long long)g * cpg) * HW;
+  const float4* xg = reinterpret_cast<const float4*>(x + base);
+  float4* yg = reinterpret_cast<float4*>(y + base);
+  if (tid < 64) psum[tid] = 0.f;
+  const float pivot = x[base];
+  float4 v[MAXQ];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < MAXQ; ++q) {
+    const int r = wave + q * NW;
+    const int cl = r / RPC, i = (r % RPC) * 64 + lane;
+    const bool ok = r < rows && i < HWV;
+    v[q] = ok ? xg[(long long)cl * HWV + i] : make_float4(pivot, pivot, pivot, pivot);
+    const float a = v[q].x - pivot, b = v[q].y - pivot, c = v[q].z - pivot, d = v[q].w - pivot;
+    s1 += (a + b) + (c + d);
+    s2 += (a * a + b * b) + (c * c + d * d);
+  }
+  const float L = (float)(cpg * HW);
+  s1 = block_sum(s1, red) / L;
+  s2 = block_sum(s2, red) / L;
+  const float mean = pivot + s1;
+  const float rstd = rsqrtf(fmaxf(s2 - s1 * s1, 0.f) + eps);
+  if (tid == 0) {
+    stats[2 * blockIdx.x] = mean;
+    stats[2 * blockIdx.x + 1] = rstd;
+  }
+#pragma unroll
+  for (int q = 0; q < MAXQ; ++q) {
+    const int r = wave + q * NW;
+    const int cl = r / RPC, i = (r % RPC) * 64 + lane;
+    const bool ok = r < rows && i < HWV;
+    const int c = g * cpg + (r < rows ? cl : 0);
+    const float ga = gamma[c] * rstd, be = beta[c] - mean * rstd * gamma[c];
+    float4 o;
+    float u;
+    u = v[q].x * ga + be; o.x = u * fast_sigmoid(u);
+    u = v[q].y * ga + be; o.y = u * fast_sigmoid(u);
+    u = v[q].z * ga + be; o.z = u * fast_sigmoid(u);
+    u = v[q].w * ga + be; o.w = u * fast_sigmoid(u);
+    if (ok) yg[(long long)cl * HWV + i] = o;
+    if (pooled) {
+      float ps = ok ? (o.x + o.y) + (o.z + o.w) : 0.f;
+      ps = wave_sum(ps);
+      if (lane == 0 && r < rows) atomicAdd(&psum[cl], ps);
+    }
+  }
+  if (pooled) {
+    __syncthreads();
+    if (tid < cpg) pooled[(long long)n * C + g * cpg + tid] = psum[tid] / (float)HW;
+  }
+}
+
+template <int MODE, int MAXQ>
+__global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_reg_kernel(const float* __restrict__ x,
+                                                                       const float* __restrict__ gamma,
+                                                                       const float* __restrict__ beta,
+                                                                       const float* __restrict__ stats,
+                                                                       const float* __restrict__ dA, long long st_dA,
+                                                                       GateBwd gb, float* __restrict__ dx,
+                                                                       float* __restrict__ dgamma,
+                                                                       float* __restrict__ dbeta, int C, int HW, int G) {
+  __shared__ float csd[64], csdx[64], tot[2];
+  const int n = blockIdx.x / G, g = blockIdx.x % G;
+  const int cpg = C / G;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = GN_THREADS / 64;
+  const int HWV = HW / 4, RPC = (HWV + 63) / 64, rows = cpg * RPC;
+  const float mean = stats[2 * blockIdx.x], rstd = stats[2 * blockIdx.x + 1];
+  const float inv_hw = 1.f / (float)HW, inv_c = 1.f / (float)C;
+  if (tid < 64) { csd[tid] = 0.f; csdx[tid] = 0.f; }
+  __syncthreads();
+  float4 xh[MAXQ], du[MAXQ];
+#pragma unroll
+  for (int q = 0; q < MAXQ; ++q) {
+    const int r = wave + q * NW;
+    const int cl = r < rows ? r / RPC : 0, i = (r % RPC) * 64 + lane;
+    const bool ok = r < rows && i < HWV;
+    const int c = g * cpg + cl;
+    const long long nc = (long long)n * C + c;
+    const long long e = nc * HWV + (ok ? i : 0);               // quad index inside [N,C,HW]
+    const float ga = gamma[c], be = beta[c];
+    const float4 xv = reinterpret_cast<const float4*>(x)[e];
+    float4 up;
+    if (MODE == 0) {
+      up = reinterpret_cast<const float4*>(dA + (long long)n * st_dA + (long long)c * HW)[ok ? i : 0];
+    } else {
+      const long long m0 = (long long)n * HWV + (ok ? i : 0);
+      const float4 a2v = reinterpret_cast<const float4*>(gb.a2)[e], dov = reinterpret_cast<const float4*>(gb.dout)[e];
+      const float4 gtv = reinterpret_cast<const float4*>(gb.gate)[m0], ctv = reinterpret_cast<const float4*>(gb.cnt)[m0];
+      const float4 dav = reinterpret_cast<const float4*>(gb.dmap)[2 * (long long)n * HWV + (ok ? i : 0)];
+      const float4 dmv = reinterpret_cast<const float4*>(gb.dmap)[(2 * (long long)n + 1) * HWV + (ok ? i : 0)];
+      const float4 mxv = reinterpret_cast<const float4*>(gb.umax)[(2 * (long long)n + 1) * HWV + (ok ? i : 0)];
+      const float sc = gb.s[nc], dpl = gb.dpool[nc] * inv_hw;
+      auto one = [&](float a2e, float doe, float gte, float dae, float dme, float mxe, float cte) {
+        const float U = a2e * sc;                      // bit-exact forward product: operand of the tie test
+        float dU = doe * gte + dae * inv_c;
+        if (U == mxe) dU += dme / cte;
+        return dU * sc + dpl;
+      };
+      up.x = one(a2v.x, dov.x, gtv.x, dav.x, dmv.x, mxv.x, ctv.x);
+      up.y = one(a2v.y, dov.y, gtv.y, dav.y, dmv.y, mxv.y, ctv.y);
+      up.z = one(a2v.z, dov.z, gtv.z, dav.z, dmv.z, mxv.z, ctv.z);
+      up.w = one(a2v.w, dov.w, gtv.w, dav.w, dmv.w, mxv.w, ctv.w);
+    }
+    float sd = 0.f, sdx = 0.f;
+    auto elem = [&](float xe, float upe, float& xho, float& duo) {
+      const float h = (xe - mean) * rstd;
+      const float u = h * ga + be;
+      const float sg = fast_sigmoid(u);
+      const float d = ok ? upe * (sg * (1.f + u * (1.f - sg))) : 0.f;
+      xho = h; duo = d; sd += d; sdx += d * h;
+    };
+    elem(xv.x, up.x, xh[q].x, du[q].x);
+    elem(xv.y, up.y, xh[q].y, du[q].y);
+    elem(xv.z, up.z, xh[q].z, du[q].z);
+    elem(xv.w, up.w, xh[q].w, du[q].w);
+    sd = wave_sum(sd);
+    sdx = wave_sum(sdx);
+    if (lane == 0 && r < rows) {
+      atomicAdd(&csd[cl], sd);
+      atomicAdd(&csdx[cl], sdx);
+    }
+  }
+  __syncthreads();
+  if (tid < cpg) {
+    const int c = g * cpg + tid;
+    unsafeAtomicAdd(dbeta + c, csd[tid]);
+    unsafeAtomicAdd(dgamma + c, csdx[tid]);
+  }
+  if (tid == 0) {
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < cpg; ++k) {
+      const float ga = gamma[g * cpg + k];
+      a += csd[k] * ga;
+      b += csdx[k] * ga;
+    }
+    const float m = 1.f / (float)(cpg * HW);
+    tot[0] = a * m;
+    tot[1] = b * m;
+  }
+  __syncthreads();
+  const float s1 = tot[0], s2 = tot[1];
+#pragma unroll
+  for (int q = 0; q < MAXQ; ++q) {
+    const int r = wave + q * NW;
+    const int cl = r < rows ? r / RPC : 0, i = (r % RPC) * 64 + lane;
+    const bool ok = r < rows && i < HWV;
+    const int c = g * cpg + cl;
+    const float ga = gamma[c];
+    float4 o;
+    o.x = rstd * (du[q].x * ga - s1 - xh[q].x * s2);
+    o.y = rstd * (du[q].y * ga - s1 - xh[q].y * s2);
+    o.z = rstd * (du[q].z * ga - s1 - xh[q].z * s2);
+    o.w = rstd * (du[q].w * ga - s1 - xh[q].w * s2);
+    if (ok) reinterpret_cast<float4*>(dx)[((long long)n * C + c) * HWV + i] = o;
+  }
+}
+
+// number of register slots (64-quad rows per wave) a (cpg, hw) group needs with the float4 register path; 0 = n/a
+static inline int gn_reg_slots(int cpg, int hw) {
+  if (hw % 4 || cpg > 64) return 0;
+  const int rpc = (hw / 4 + 63) / 64;
+  return (cpg * rpc + GN_THREADS / 64 - 1) / (GN_THREADS / 64);
+}
+
 }  // namespace
 
 extern "C" {
@@ -232,6 +416,16 @@ int cm_gn_silu_fwd(const float* x, const float* gamma, const float* beta, float*
   const bool vec = (hw % 4) == 0;
   const bool narrow = (vec ? hw / 4 : hw) <= 64 && (c / groups) >= 8;   // short rows: 16 lanes per channel
   hipStream_t st = (hipStream_t)stream;
+  const int slots = gn_reg_slots(c / groups, hw);
+  static const bool reg_fwd = getenv("CM_GN_FWD_REG") != nullptr;   // measured slower than the streaming kernel
+  if (reg_fwd && slots > 0 && slots <= 14 && !narrow) {
+    if (slots <= 7)
+      gn_silu_fwd_reg_kernel<7><<<n * groups, GN_THREADS, 0, st>>>(x, gamma, beta, y, stats, pooled, c, hw, groups, eps);
+    else
+      gn_silu_fwd_reg_kernel<14><<<n * groups, GN_THREADS, 0, st>>>(x, gamma, beta, y, stats, pooled, c, hw, groups, eps);
+    CM_CHECK_LAUNCH();
+    return 0;
+  }
 #define GN_FWD(V, L) gn_silu_fwd_kernel<V, L><<<n * groups, GN_THREADS, 0, st>>>(x, gamma, beta, y, stats, pooled, c, hw, groups, eps)
   if (vec) { if (narrow) GN_FWD(true, 16); else GN_FWD(true, 64); }
   else     { if (narrow) GN_FWD(false, 16); else GN_FWD(false, 64); }
@@ -248,6 +442,15 @@ int cm_gn_silu_bwd(const float* x, const float* gamma, const float* beta, const 
   const bool vec = (hw % 4) == 0 && (st_dA % 4) == 0;
   const bool narrow = (vec ? hw / 4 : hw) <= 64 && (c / groups) >= 8;
   hipStream_t st = (hipStream_t)stream;
+  const int slots = gn_reg_slots(c / groups, hw);
+  if (vec && slots > 0 && slots <= 14 && !narrow) {
+    if (slots <= 7)
+      gn_silu_bwd_reg_kernel<0, 7><<<n * groups, GN_THREADS, 0, st>>>(x, gamma, beta, stats, dA, st_dA, gb, dx, dgamma, dbeta, c, hw, groups);
+    else
+      gn_silu_bwd_reg_kernel<0, 14><<<n * groups, GN_THREADS, 0, st>>>(x, gamma, beta, stats, dA, st_dA, gb, dx, dgamma, dbeta, c, hw, groups);
+    CM_CHECK_LAUNCH();
+    return 0;
+  }
 #define GN_BWD(V, L) gn_silu_bwd_kernel<0, V, L><<<n * groups, GN_THREADS, 0, st>>>(x, gamma, beta, stats, dA, st_dA, gb, dx, dgamma, dbeta, c, hw, groups)
   if (vec) { if (narrow) GN_BWD(4, 16); else GN_BWD(4, 64); }
   else     { if (narrow) GN_BWD(1, 16); else GN_BWD(1, 64); }
@@ -266,6 +469,15 @@ int cm_gn_silu_bwd_gated(const float* x, const float* gamma, const float* beta, 
   const bool vec = (hw % 4) == 0;
   const bool narrow = (vec ? hw / 4 : hw) <= 64 && (c / groups) >= 8;
   hipStream_t st = (hipStream_t)stream;
+  const int slots = gn_reg_slots(c / groups, hw);
+  if (vec && slots > 0 && slots <= 14 && !narrow) {
+    if (slots <= 7)
+      gn_silu_bwd_reg_kernel<1, 7><<<n * groups, GN_THREADS, 0, st>>>(x, gamma, beta, stats, nullptr, 0, gb, dx, dgamma, dbeta, c, hw, groups);
+    else
+      gn_silu_bwd_reg_kernel<1, 14><<<n * groups, GN_THREADS, 0, st>>>(x, gamma, beta, stats, nullptr, 0, gb, dx, dgamma, dbeta, c, hw, groups);
+    CM_CHECK_LAUNCH();
+    return 0;
+  }
 #define GN_BWD(V, L) gn_silu_bwd_kernel<1, V, L><<<n * groups, GN_THREADS, 0, st>>>(x, gamma, beta, stats, nullptr, 0, gb, dx, dgamma, dbeta, c, hw, groups)
   if (vec) { if (narrow) GN_BWD(4, 16); else GN_BWD(4, 64); }
   else     { if (narrow) GN_BWD(1, 16); else GN_BWD(1, 64); }

@@ -465,13 +465,16 @@ __global__ void wgrad_unpack_batch_kernel(const long long* __restrict__ descs, i
   float* dw = reinterpret_cast<float*>(r[1]);
   const int cout = (int)r[2], ctot = (int)r[3];
   const int b0 = (int)r[7], nb = (int)descs[(d + 1) * 8 + 7] - b0;
-  const long long total = (long long)cout * ctot * 9;
-  for (long long i = (long long)(blockIdx.x - b0) * blockDim.x + threadIdx.x; i < total; i += (long long)nb * blockDim.x) {
-    const int tap = (int)(i % 9);
-    const long long oc = i / 9;
-    const int c = (int)(oc % ctot);
-    const int o = (int)(oc / ctot);
-    dw[i] = scale * g[((long long)o * 9 + tap) * ctot + c];
+  // one thread per (o, c): nine coalesced tap-major reads, nine consecutive writes
+  const long long pairs = (long long)cout * ctot;
+  for (long long i = (long long)(blockIdx.x - b0) * blockDim.x + threadIdx.x; i < pairs; i += (long long)nb * blockDim.x) {
+    const int c = (int)(i % ctot);
+    const long long o = i / ctot;
+    float v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) v[t] = g[(o * 9 + t) * ctot + c];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dw[i * 9 + t] = scale * v[t];
   }
 }
 

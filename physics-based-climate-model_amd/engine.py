@@ -67,7 +67,7 @@ class Plan:
                 raise RuntimeError("parameters must be contiguous")
             self.pk[key] = self.wp_arena[o:o + sz]
             rec.append([w.data_ptr(), self.pk[key].data_ptr(), w.shape[0], w.shape[1], off, cin, dg, blk])
-            blk += max(1, min(64, (sz + 2047) // 2048))
+            blk += max(1, min(512, (sz + 1023) // 1024))
             o += sz
         rec.append([0, 0, 0, 0, 0, 0, 0, blk])
         self.pack_table = torch.tensor(rec, dtype=torch.int64).to(dev)
@@ -84,7 +84,7 @@ class Plan:
                 sz = p[n].numel()
                 self.gw[n] = self.g_arena[o:o + sz].view(co, 9, ci)
                 rec.append([self.gw[n].data_ptr(), g[n].data_ptr(), co, ci, 0, 0, 0, blk])
-                blk += max(1, min(64, (sz + 2047) // 2048))
+                blk += max(1, min(512, (sz // 9 + 255) // 256))
                 o += sz
             rec.append([0, 0, 0, 0, 0, 0, 0, blk])
             self.unpack_table = torch.tensor(rec, dtype=torch.int64).to(dev)
