@@ -12,6 +12,7 @@ Layout decisions:
     sequential.  Gate buffers are [B,T,4*Ch,h,w]; step t works on the strided slice [:, t] in place;
   * torch.cat([up, skip]) is never materialised: the conv kernels take two input pointers.
 """
+import os
 from typing import Dict, Optional
 
 import torch
@@ -145,7 +146,8 @@ def _block_fwd(p: Params, pk, prefix: str, x0: Tensor, x1: Optional[Tensor], sav
     return out, ctx
 
 
-def _block_bwd(p: Params, pk, g: Params, gw: Params, prefix: str, ctx: _BlockCtx, dout: Tensor, need_dx: bool = True):
+def _block_bwd(p: Params, pk, g: Params, gw: Params, ss: "_SideStream", prefix: str, ctx: _BlockCtx, dout: Tensor,
+               need_dx: bool = True):
     """Returns d(input) as one tensor [N, C0+C1, H, W] (or None); parameter gradients are accumulated into ``g``."""
     co = ctx.y1.shape[1]
     w1, w2, w7 = p[prefix + "se.fc.0.weight"], p[prefix + "se.fc.2.weight"], p[prefix + "spat.conv.weight"]
@@ -155,12 +157,12 @@ def _block_bwd(p: Params, pk, g: Params, gw: Params, prefix: str, ctx: _BlockCtx
     dy2 = ops.gn_silu_bwd_gated(ctx.y2, p[prefix + "body.4.weight"], p[prefix + "body.4.bias"], ctx.st2, ctx.a2, dout,
                                 ctx.gate, dmap, ctx.fmap, cnt, ctx.s, dpool, g[prefix + "body.4.weight"],
                                 g[prefix + "body.4.bias"])
-    ops.wgrad3x3(ctx.a1, dy2, gw[prefix + "body.3.weight"])
+    ss.run(lambda: ops.wgrad3x3(ctx.a1, dy2, gw[prefix + "body.3.weight"]), ctx.a1, dy2)
     da1 = ops.conv3x3(dy2, pk[prefix + "body.3.weight/d"], co)
     dy1 = ops.gn_silu_bwd(ctx.y1, p[prefix + "body.1.weight"], p[prefix + "body.1.bias"], ctx.st1, da1,
                           g[prefix + "body.1.weight"], g[prefix + "body.1.bias"])
     ci = ctx.x0.shape[1] + (0 if ctx.x1 is None else ctx.x1.shape[1])
-    ops.wgrad3x3(ctx.x0, dy1, gw[prefix + "body.0.weight"], x1=ctx.x1)
+    ss.run(lambda: ops.wgrad3x3(ctx.x0, dy1, gw[prefix + "body.0.weight"], x1=ctx.x1), ctx.x0, ctx.x1, dy1)
     if not need_dx:
         return None
     return ops.conv3x3(dy1, pk[prefix + "body.0.weight/d"], ci)
@@ -187,6 +189,44 @@ def _unpack_into(gw: Tensor, dst: Tensor) -> None:
 
 
 # ------------------------------------------------------------------------------------------------- whole model
+class _SideStream:
+    """Second HIP stream for the weight-gradient GEMMs.  They depend only on (layer input, upstream gradient) and
+    feed nothing but the final unpack, so they run beside the main chain (data gradients + the HBM-bound
+    normalisation / gate kernels) and fill the matrix pipes while those stream memory.  Works eagerly and under
+    hipGraph capture (fork/join through events).  Tensors handed to the side stream are kept alive until the join."""
+
+    _streams: Dict[int, "torch.cuda.Stream"] = {}
+
+    def __init__(self, device, enabled: bool):
+        self.enabled = enabled
+        self.keep = []
+        if enabled:
+            idx = device.index if device.index is not None else torch.cuda.current_device()
+            if idx not in _SideStream._streams:
+                _SideStream._streams[idx] = torch.cuda.Stream(device=device)
+            self.side = _SideStream._streams[idx]
+            self.main = torch.cuda.current_stream(device)
+
+    def run(self, fn, *tensors):
+        if not self.enabled:
+            fn()
+            return
+        self.keep.extend(t for t in tensors if t is not None)
+        self.side.wait_stream(self.main)
+        with torch.cuda.stream(self.side):
+            fn()
+
+    def join(self):
+        if self.enabled:
+            self.main.wait_stream(self.side)
+        self.keep.clear()
+
+
+# Measured on MI355X (config 2): overlapping is 5 % SLOWER than the serial chain (the 12-wave, ~100 KB-LDS weight-gradient
+# workgroups do not co-reside with the conv workgroups, so the two kernels time-slice the CUs), hence off by default.
+OVERLAP_WGRAD = os.environ.get("CM_OVERLAP_WGRAD", "0") != "0"
+
+
 class Saved:
     """Everything the backward needs from one forward."""
     __slots__ = ("B", "T", "enc", "pools_in", "s4", "gx", "hprev", "call", "bott", "ups", "up_in", "d1", "x_shape")
@@ -254,6 +294,7 @@ def backward(p: Params, pk, g: Params, sv: Saved, dpred: Tensor, need_dx: bool =
     plan = get_plan(p, g, need_dx)
     gw = plan.gw
     plan.zero_staging()
+    ss = _SideStream(dpred.device, OVERLAP_WGRAD)
     B, T = sv.B, sv.T
     c1, c2, c3, c4 = sv.enc
     cu3, cu2, cu1 = sv.ups
@@ -261,13 +302,13 @@ def backward(p: Params, pk, g: Params, sv: Saved, dpred: Tensor, need_dx: bool =
 
     # ---- head + decoder --------------------------------------------------------------------------------
     dd1 = ops.head_bwd(dpred, sv.d1, p["head.weight"], g["head.weight"], g["head.bias"])
-    dcat1 = _block_bwd(p, pk, g, gw, "up1.conv.", cu1, dd1)
+    dcat1 = _block_bwd(p, pk, g, gw, ss, "up1.conv.", cu1, dd1)
     b1 = cu1.x0.shape[1]
     dd2 = ops.convT2x2_bwd(d2, p["up1.up.weight"], dcat1[:, :b1], g["up1.up.weight"], g["up1.up.bias"])
-    dcat2 = _block_bwd(p, pk, g, gw, "up2.conv.", cu2, dd2)
+    dcat2 = _block_bwd(p, pk, g, gw, ss, "up2.conv.", cu2, dd2)
     b2 = cu2.x0.shape[1]
     dd3 = ops.convT2x2_bwd(d3, p["up2.up.weight"], dcat2[:, :b2], g["up2.up.weight"], g["up2.up.bias"])
-    dcat3 = _block_bwd(p, pk, g, gw, "up3.conv.", cu3, dd3)
+    dcat3 = _block_bwd(p, pk, g, gw, ss, "up3.conv.", cu3, dd3)
     b3 = cu3.x0.shape[1]
     dbott = ops.convT2x2_bwd(bott, p["up3.up.weight"], dcat3[:, :b3], g["up3.up.weight"], g["up3.up.bias"])
 
@@ -285,19 +326,23 @@ def backward(p: Params, pk, g: Params, sv: Saved, dpred: Tensor, need_dx: bool =
             dhrec = ops.conv3x3(gx[:, t], pk["lstm.h/d"], ch)
     dA = gx.view(B * T, 4 * ch, h8, w8)            # now holds d(pre-activations) for every (b, t)
     gl = gw["convlstm.cell.conv.weight"]
-    ops.wgrad3x3(sv.s4, dA, gl, c_off=0)
-    if T > 1:
-        ops.wgrad3x3(hprev.view(B * T, ch, h8, w8), dA, gl, c_off=cx)   # hprev[:, 0] == 0 contributes nothing
+
+    def lstm_wgrads():
+        ops.wgrad3x3(sv.s4, dA, gl, c_off=0)
+        if T > 1:
+            ops.wgrad3x3(hprev.view(B * T, ch, h8, w8), dA, gl, c_off=cx)   # hprev[:, 0] == 0 contributes nothing
+    ss.run(lstm_wgrads, sv.s4, dA, hprev)
     ops.channel_sum(dA, g["convlstm.cell.conv.bias"])
     ds4 = ops.conv3x3(dA, pk["lstm.x/d"], cx)
 
     # ---- encoder ---------------------------------------------------------------------------------------
-    dp3 = _block_bwd(p, pk, g, gw, "enc4.conv.", c4, ds4)
+    dp3 = _block_bwd(p, pk, g, gw, ss, "enc4.conv.", c4, ds4)
     ds3 = ops.maxpool2_bwd(c3.out, dp3, dcat3[:, b3:], t=T)
-    dp2 = _block_bwd(p, pk, g, gw, "enc3.conv.", c3, ds3)
+    dp2 = _block_bwd(p, pk, g, gw, ss, "enc3.conv.", c3, ds3)
     ds2 = ops.maxpool2_bwd(c2.out, dp2, dcat2[:, b2:], t=T)
-    dp1 = _block_bwd(p, pk, g, gw, "enc2.conv.", c2, ds2)
+    dp1 = _block_bwd(p, pk, g, gw, ss, "enc2.conv.", c2, ds2)
     ds1 = ops.maxpool2_bwd(c1.out, dp1, dcat1[:, b1:], t=T)
-    dx = _block_bwd(p, pk, g, gw, "enc1.", c1, ds1, need_dx=need_dx)
+    dx = _block_bwd(p, pk, g, gw, ss, "enc1.", c1, ds1, need_dx=need_dx)
+    ss.join()
     plan.unpack()
     return dx.view(sv.x_shape) if dx is not None else None

@@ -36,6 +36,7 @@ def _pick(key, candidates, launch, fallback):
         return _TUNED[key]
     if not AUTOTUNE or torch.cuda.is_current_stream_capturing():
         return fallback
+    torch.cuda.synchronize()      # drain every stream so the candidates are timed alone on the device
     best, best_t = fallback, float("inf")
     for cfg in (range(candidates) if isinstance(candidates, int) else candidates):
         if launch(cfg) != 0:          # configuration not applicable to this call (argument error): skip it
