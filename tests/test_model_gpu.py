@@ -178,3 +178,63 @@ def test_checkpoint_roundtrip(amd):
     x = torch.randn(2, 3, 5, 16, 24, device="cuda")
     with torch.no_grad():
         assert rel_l2(m(x), m2(x)) < 1e-6
+
+
+def _se_margin(P, x):
+    """Smallest |pre-ReLU SE hidden activation| relative to the largest one, over every SE block of the oracle's
+    forward.  A hidden unit sitting at ~0 makes the ReLU mask (hence the gradients) flip between any two fp32
+    evaluations, which is a property of the model, not of a kernel; such parameter sets are not used for parity."""
+    import oracle.cpu_ref as ref
+    seen = []
+    orig = ref.se_block
+
+    def spy(xx, w1, w2):
+        z = F.conv2d(xx.mean(dim=(2, 3), keepdim=True), w1)
+        seen.append((z.abs().min() / z.abs().max().clamp_min(1e-30)).item())
+        return orig(xx, w1, w2)
+    ref.se_block = spy
+    try:
+        with torch.no_grad():
+            oracle.model_forward(P, x)
+    finally:
+        ref.se_block = orig
+    return min(seen)
+
+
+@pytest.mark.parametrize("shape", [
+    dict(base=64, T=3, B=2, H=48, W=72),        # BASELINE config 3's channel widths (base 64), short sequence
+    dict(base=16, T=2, B=1, H=192, W=288, grad_tol=3e-3),   # BASELINE config 5's upscaled grid (LDS-tile stress)
+    dict(base=64, T=2, B=1, H=96, W=144),       # base 64 on a 2x grid
+])
+def test_other_baseline_shapes_vs_oracle(amd, shape):
+    """Configs 3 and 5 of BASELINE.json are parity cases: same kernels, wider channels / larger grids, against the
+    CPU oracle on seeded inputs (sizes cut so the oracle finishes in seconds).
+
+    The 192x288 case uses a looser GRADIENT tolerance (loss/output stay at 1e-5 / 1e-4): with 110 592 pixels per frame
+    the CBAM channel-max has near-ties (top-2 gap ~1e-7) at about one pixel per block, where ANY two fp32 evaluations
+    may pick different argmax channels; one flipped pixel moves the strongly cancelling SE gradient sums by ~0.5 %
+    (tools/debug_block.py decomposes exactly this: kernel sums equal the fp64 sum of their own inputs to 6e-7)."""
+    in_ch, out_ch = 5, 2
+    base, T, B, H, W = shape["base"], shape["T"], shape["B"], shape["H"], shape["W"]
+    gen = torch.Generator("cpu").manual_seed(321)
+    x = torch.randn(B, T, in_ch, H, W, generator=gen); y = torch.randn(B, out_ch, H, W, generator=gen)
+    for salt in range(9, 30):
+        P = oracle.closed_form_params(in_ch, out_ch, base, salt=salt)
+        if _se_margin(P, x) > 2e-3:
+            break
+    else:
+        pytest.skip("no parameter set with a safe ReLU margin found")
+    pc = {k: v.clone().requires_grad_() for k, v in P.items()}
+    lc = oracle.training_loss(pc, x, y); lc.backward()
+    m = _make(amd, in_ch, out_ch, base, T, salt=salt)
+    pred = m(x.cuda()); lg = F.mse_loss(pred, y.cuda()); lg.backward()
+    assert abs(lg.item() - lc.item()) < 1e-5 * abs(lc.item())
+    named = dict(m.named_parameters())
+    worst = 0.0
+    for k in pc:
+        if pc[k].grad is not None:
+            e = rel_l2(named[k].grad, pc[k].grad)
+            worst = max(worst, e)
+            assert e < shape.get("grad_tol", TOL), (k, e)
+    assert rel_l2(pred, oracle.model_forward(P, x)) < TOL
+    print(f"{shape}: worst grad rel-L2 {worst:.2e}")
