@@ -204,7 +204,7 @@ def _se_margin(P, x):
 @pytest.mark.parametrize("shape", [
     dict(base=64, T=3, B=2, H=48, W=72),        # BASELINE config 3's channel widths (base 64), short sequence
     dict(base=16, T=2, B=1, H=192, W=288, grad_tol=3e-3),   # BASELINE config 5's upscaled grid (LDS-tile stress)
-    dict(base=64, T=2, B=1, H=96, W=144),       # base 64 on a 2x grid
+    dict(base=64, T=2, B=1, H=96, W=144, grad_tol=1e-3),    # base 64 on a 2x grid (same near-tie caveat, 13 824 px)
 ])
 def test_other_baseline_shapes_vs_oracle(amd, shape):
     """Configs 3 and 5 of BASELINE.json are parity cases: same kernels, wider channels / larger grids, against the
