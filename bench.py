@@ -21,7 +21,23 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: Peak FP32 (matrix), dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: Peak BF16 MFMA, dense
 PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak BW
+
+
+def load_pmc_traffic(launcher):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the
+    gfx950 correction calibrated on this code's own 4-byte-per-lane kernels, + WRITE_SIZE); None if not collected."""
+    fam = {"cm_conv3x3_split": "conv3x3_split_kernel", "cm_conv3x3": "conv3x3_mfma_kernel"}[launcher]
+    for path in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))[::-1]:
+        try:
+            d = json.load(open(path)).get(fam)
+            if d:
+                return {"bytes_per_launch": round((2.0 * d["fetch_kib_per_launch"] + d["write_kib_per_launch"]) * 1024),
+                        "source": os.path.relpath(path, ROOT)}
+        except Exception:
+            pass
+    return None
 
 
 def train_flops_per_sample(b, T, H, W, cin=5, cout=2):
@@ -161,14 +177,24 @@ def main():
                 kernels[name]["tflops"] = round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2)
             if d["bytes"] and not d["flops"]:
                 kernels[name]["gbps"] = round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1)
-        c = summ.get("cm_conv3x3")
-        if c:
-            ach = c["flops"] / (c["ms"] * 1e-3) / 1e12
-            roof = {"kernel": "conv3x3_mfma_kernel (cm_conv3x3: forward + data-gradient launches)", "bound": "mfma",
-                    "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                    "launches_per_step": c["calls"] / args.profile_steps,
-                    "avg_launch_us": round(c["ms"] * 1e3 / c["calls"], 2)}
+        # dominant kernel = the conv family that takes the most time in the step
+        cands = [(n, summ[n]) for n in ("cm_conv3x3_split", "cm_conv3x3") if n in summ]
+        if cands:
+            name, c = max(cands, key=lambda kv: kv[1]["ms"])
+            alg = c["flops"] / (c["ms"] * 1e-3) / 1e12
+            if name == "cm_conv3x3_split":
+                # bf16x6: six bf16 MFMAs are executed per algorithmic (fp32-equivalent) MAC group
+                roof = {"kernel": "conv3x3_split_kernel (cm_conv3x3_split: forward + data-gradient launches, bf16x6)",
+                        "bound": "mfma", "achieved": round(6 * alg, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(6 * alg / PEAK_BF16_MFMA_TFLOPS, 4),
+                        "mfma_dtype": "bf16 (3 pieces per fp32 operand, 6 products, fp32 accumulate)",
+                        "algorithmic_tflops": round(alg, 2)}
+            else:
+                roof = {"kernel": "conv3x3_mfma_kernel (cm_conv3x3: forward + data-gradient launches)",
+                        "bound": "mfma", "achieved": round(alg, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(alg / PEAK_FP32_MFMA_TFLOPS, 4)}
+            roof.update({"traffic": load_pmc_traffic(name), "launches_per_step": c["calls"] / args.profile_steps,
+                         "avg_launch_us": round(c["ms"] * 1e3 / c["calls"], 2)})
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

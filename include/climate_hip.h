@@ -47,6 +47,18 @@ int cm_conv3x3(const float* in0, long long st0, int c0, const float* in1, long l
                const float* bias, const float* resid, long long st_resid, float* out, long long st_out, int n, int h,
                int w, int cout, int config, cm_stream stream);
 
+/* ---- conv3x3 on the bf16 matrix cores with fp32-equivalent accuracy ("bf16x6") --------------------------------- *
+ * Same contract as cm_conv3x3 (same reference call sites), operands split into three bf16 pieces each, six bf16
+ * MFMAs per 16-deep k-step, fp32 accumulation.  wps comes from cm_pack_conv3x3_split_batch (descriptor records as
+ * cm_pack_conv3x3_batch, with the wp field pointing at cm_conv3x3_split_packed_bytes() bytes).  When in1 is given,
+ * c0 must be a multiple of 32.  config in [0, cm_conv3x3_split_num_configs()).                                    */
+int cm_conv3x3_split_num_configs(void);
+long long cm_conv3x3_split_packed_bytes(int k_channels, int out_channels);
+int cm_pack_conv3x3_split_batch(const void* descs_dev, int ndesc, int total_blocks, cm_stream stream);
+int cm_conv3x3_split(const float* in0, long long st0, int c0, const float* in1, long long st1, int c1,
+                     const void* wps, const float* bias, const float* resid, long long st_resid, float* out,
+                     long long st_out, int n, int h, int w, int cout, int config, cm_stream stream);
+
 /* ---- conv3x3 weight gradient ------------------------------------------------------------------------------- *
  * convolution_backward (weight) of the convs above.  Accumulates (fp32 atomics) into a tap-major staging buffer
  * g[cout][9][ctot] that the caller zeroes once per step; cm_wgrad3x3_unpack transposes it to [cout][ctot][3][3].

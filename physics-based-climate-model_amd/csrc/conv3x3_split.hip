@@ -1,0 +1,412 @@
+// 3x3 / pad 1 convolution on the bf16 matrix cores with fp32-equivalent accuracy ("bf16x6"):
+// every fp32 operand is split into three bf16 pieces (hi, mid, lo; 24 mantissa bits in total) and the product is
+// accumulated in fp32 from the six leading piece products
+//     a*b ~= hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid           (dropped terms < 2^-24 |a*b|)
+// with v_mfma_f32_32x32x16_bf16.  gfx950 runs bf16 MFMA at 16x the fp32-MFMA rate, so six bf16 MFMAs per 16-deep
+// k-step cost 192 cycles where the fp32 kernel's eight 32x32x2 MFMAs cost 512.  tools/emulate_bf16_split.py shows on
+// the CPU that this keeps every gradient of the model within the fp32 noise floor (~5e-6 rel), whereas the 3-term
+// variant (bf16x3) sits at 9e-5 -- too close to the 1e-4 parity bound -- and is therefore not offered.
+//
+// Same role as conv3x3_mfma.hip (reference call sites src/unet.py:36,38, src/convlstm.py:9,13 and their data
+// gradients), same GEMM orientation (rows = output channels, columns = pixels, 128-byte coalesced stores), but:
+//   * K runs over 16 input channels of one tap per MFMA; a lane's fragment is 8 consecutive channels (16 bytes);
+//   * the haloed input tile is converted on the way into LDS: a thread loads 8 channels of one pixel (8 coalesced
+//     dword loads), splits them, and writes three 16-byte records Xl[piece][channel-octet][pixel];
+//   * weight fragments are pre-split by cm_pack_conv3x3_split into [piece][16-channel step][tap][octet][cout][8]
+//     and read straight from global memory (L1/L2 resident, one k-step ahead, ping-pong registers), no LDS.
+#include "common.h"
+#include "../../include/climate_hip.h"
+
+namespace {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SKC = 32;   // input channels per LDS stage (two 16-channel MFMA k-steps per tap)
+
+__device__ __forceinline__ unsigned bf16_rne(float f) {   // round-to-nearest-even bf16 bits (finite inputs)
+  const unsigned u = __float_as_uint(f);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+// split v into three bf16 pieces; returns them as 16-bit values
+__device__ __forceinline__ void split3(float v, unsigned& h, unsigned& m, unsigned& l) {
+  h = bf16_rne(v);
+  const float r1 = v - __uint_as_float(h << 16);
+  m = bf16_rne(r1);
+  const float r2 = r1 - __uint_as_float(m << 16);
+  l = bf16_rne(r2);
+}
+
+struct SplitArgs {
+  const float* in0;
+  const float* in1;
+  long long st0, st1;
+  int C0, C1;
+  const u32x4* wps;    // split weights: [3][nsteps][9][2][CoutP] records of 8 bf16
+  const float* bias;
+  const float* resid;
+  float* out;
+  long long sto;
+  int N, H, W, Cout, CoutP, nsteps, tiles_x, tiles_y;   // nsteps = 16-channel k-steps = 2 * nchunks
+};
+
+template <int TH, int TW, int S, int WAVES, int NPT, int WM, bool DUAL>
+__global__ __launch_bounds__(WAVES * 64) void conv3x3_split_kernel(SplitArgs a) {
+  constexpr int THREADS = WAVES * 64;
+  constexpr int PITCH = TW + 2;
+  constexpr int SS = (TH + 2) * PITCH;
+  constexpr int PH = S * SS;                     // haloed pixels per stage
+  constexpr int ITEMS = PH * 4;                  // (pixel, channel octet) records per 32-channel stage
+  constexpr int NI = (ITEMS + THREADS - 1) / THREADS;
+  constexpr int BCO = 32 * WM;
+  constexpr int PIX = S * TH * TW;
+  static_assert(WAVES * NPT * 32 >= PIX, "block does not cover its pixel set");
+
+  __shared__ u32x4 Xl[3 * 4 * PH];               // [piece][octet][pixel]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  const float* const a_in0 = a.in0;
+  const float* const a_in1 = a.in1;
+  const long long a_st0 = a.st0, a_st1 = a.st1;
+  const int a_C0 = a.C0, a_C1 = a.C1, a_CoutP = a.CoutP, nsteps = a.nsteps;
+  const u32x4* const a_wps = a.wps;
+
+  int bx = blockIdx.x;
+  const int tx = bx % a.tiles_x;
+  bx /= a.tiles_x;
+  const int ty = bx % a.tiles_y;
+  const int g = bx / a.tiles_y;
+  const int x0 = tx * TW, y0 = ty * TH, n0 = g * S;
+  const int co0 = blockIdx.y * BCO;
+  const int HW = a.H * a.W;
+  const int nchunks = nsteps / 2;
+
+  // ---- stage-invariant staging offsets: item -> (octet, pixel) ----
+  int goff0[NI];
+  int goff1[DUAL ? NI : 1];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int e = tid + i * THREADS;
+    const int pix = e % PH;
+    const int s = pix / SS, r2 = pix % SS;
+    const int row = r2 / PITCH, col = r2 % PITCH;
+    const int gy = y0 - 1 + row, gx = x0 - 1 + col;
+    const bool ok = (e < ITEMS) && (n0 + s < a.N) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    const int sp = gy * a.W + gx;
+    goff0[i] = ok ? (int)(s * a.st0) + sp : -1;
+    if (DUAL) goff1[i] = ok ? (int)(s * a.st1) + sp : -1;
+  }
+
+  float xr[NI][8];
+  int cvalid_pending = 0;
+
+  auto load_chunk = [&](int chunk) {
+    const int ch0 = chunk * SKC;
+    const float* src;
+    int cvalid;
+    bool second = false;
+    if (!DUAL || ch0 < a_C0) {
+      src = a_in0 + (long long)n0 * a_st0 + (long long)ch0 * HW;
+      cvalid = a_C0 - ch0;
+    } else {
+      src = a_in1 + (long long)n0 * a_st1 + (long long)(ch0 - a_C0) * HW;
+      cvalid = a_C0 + a_C1 - ch0;
+      second = true;
+    }
+    cvalid_pending = cvalid;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int e = tid + i * THREADS;
+      const int oct = e / PH;
+      const int off = (DUAL && second) ? goff1[i] : goff0[i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = oct * 8 + j;
+        const bool ok = off >= 0 && c < cvalid;
+        xr[i][j] = src[ok ? off + c * HW : 0];          // clamped address; zero-select happens at store time
+      }
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int e = tid + i * THREADS;
+      const int oct = e / PH, pix = e % PH;
+      unsigned hh[8], mm[8], ll[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool ok = goff0[i] >= 0 && (oct * 8 + j) < cvalid_pending;
+        split3(ok ? xr[i][j] : 0.f, hh[j], mm[j], ll[j]);
+      }
+      if (e < ITEMS) {
+        u32x4 ph, pm, pl;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          ph[q] = hh[2 * q] | (hh[2 * q + 1] << 16);
+          pm[q] = mm[2 * q] | (mm[2 * q + 1] << 16);
+          pl[q] = ll[2 * q] | (ll[2 * q + 1] << 16);
+        }
+        Xl[(0 * 4 + oct) * PH + pix] = ph;
+        Xl[(1 * 4 + oct) * PH + pix] = pm;
+        Xl[(2 * 4 + oct) * PH + pix] = pl;
+      }
+    }
+  };
+
+  // ---- per-lane pixel bookkeeping ----
+  int xbase[NPT];
+  long long obase[NPT];
+  bool pvalid[NPT];
+#pragma unroll
+  for (int p = 0; p < NPT; ++p) {
+    const int q = (wave * NPT + p) * 32 + l31;
+    const bool inq = q < PIX;
+    const int qq = inq ? q : 0;
+    const int s = qq / (TH * TW), rem = qq % (TH * TW);
+    const int py = rem / TW, px = rem % TW;
+    xbase[p] = half * PH + s * SS + py * PITCH + px;      // octet = 2*sub + half -> +half*PH records
+    const int n = n0 + s, gy = y0 + py, gx = x0 + px;
+    pvalid[p] = inq && n < a.N && gy < a.H && gx < a.W;
+    obase[p] = (long long)n * a.sto + (long long)gy * a.W + gx;
+  }
+
+  f32x16 acc[WM][NPT];
+#pragma unroll
+  for (int m = 0; m < WM; ++m)
+#pragma unroll
+    for (int p = 0; p < NPT; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][p][r] = 0.f;
+
+  // A fragments: record index = ((piece*nsteps*9 + T)*2 + half)*CoutP + cout with T = step*9 + tap (linear over K)
+  const long long piece_stride = (long long)nsteps * 9 * 2 * a_CoutP;
+  const u32x4* wlane = a_wps + (long long)half * a_CoutP + co0 + l31;
+  auto load_a = [&](u32x4 (&dst)[3][WM], int T) {
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+      for (int m = 0; m < WM; ++m) dst[pc][m] = wlane[pc * piece_stride + (long long)T * 2 * a_CoutP + m * 32];
+  };
+
+  u32x4 afr[2][3][WM];
+  load_a(afr[0], 0);
+  load_chunk(0);
+  const int total_T = nsteps * 9;
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    store_chunk();
+    __syncthreads();
+    if (chunk + 1 < nchunks) load_chunk(chunk + 1);
+#pragma unroll
+    for (int st = 0; st < 18; ++st) {               // 2 sixteen-channel sub-steps x 9 taps; 18 is even: the
+      const int sub = st / 9, tap = st % 9;         // ping-pong parity is the same in every chunk
+      const int T = chunk * 18 + st;
+      if (T + 1 < total_T) load_a(afr[(st + 1) & 1], T + 1);
+      bf16x8 bf[3][NPT];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+        for (int p = 0; p < NPT; ++p) {
+          const u32x4 v = Xl[(pc * 4 + sub * 2) * PH + xbase[p] + (tap / 3) * PITCH + (tap % 3)];
+          bf[pc][p] = __builtin_bit_cast(bf16x8, v);
+        }
+#pragma unroll
+      for (int m = 0; m < WM; ++m) {
+        bf16x8 af[3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) af[pc] = __builtin_bit_cast(bf16x8, afr[st & 1][pc][m]);
+#pragma unroll
+        for (int p = 0; p < NPT; ++p) {
+          // smallest terms first
+          acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1][p], acc[m][p], 0, 0, 0);
+          acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0][p], acc[m][p], 0, 0, 0);
+          acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2][p], acc[m][p], 0, 0, 0);
+          acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0][p], acc[m][p], 0, 0, 0);
+          acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1][p], acc[m][p], 0, 0, 0);
+          acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0][p], acc[m][p], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue (same accumulator map as the fp32 kernel) ----
+  if (a.bias) {
+#pragma unroll
+    for (int m = 0; m < WM; ++m) {
+      float bv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        bv[r] = a.bias[co < a.Cout ? co : 0];
+      }
+#pragma unroll
+      for (int p = 0; p < NPT; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][p][r] += bv[r];
+    }
+  }
+  if (a.resid) {
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+      for (int p = 0; p < NPT; ++p) {
+        float rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const bool ok = pvalid[p] && co < a.Cout;
+          rv[r] = a.resid[ok ? obase[p] + (long long)co * HW : 0];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][p][r] += rv[r];
+      }
+  }
+#pragma unroll
+  for (int m = 0; m < WM; ++m)
+#pragma unroll
+    for (int p = 0; p < NPT; ++p) {
+      if (pvalid[p]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (co < a.Cout) a.out[obase[p] + (long long)co * HW] = acc[m][p][r];
+        }
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ packer
+// descs as cm_pack_conv3x3_batch: {w ptr, wps ptr, cout, cin_total, c_off, cin, dgrad, first block}
+// output record (piece, T = step*9 + tap, octet-half h, col) = 8 bf16 pieces of k-channels step*16 + h*8 + j
+__global__ void pack_split_batch_kernel(const long long* __restrict__ descs, int ndesc) {
+  int d = 0;
+  while (d + 1 < ndesc && descs[(d + 1) * 8 + 7] <= (long long)blockIdx.x) ++d;
+  const long long* r = descs + d * 8;
+  const float* w = reinterpret_cast<const float*>(r[0]);
+  u32x4* wps = reinterpret_cast<u32x4*>(r[1]);
+  const int cout = (int)r[2], cin_total = (int)r[3], c_off = (int)r[4], cin = (int)r[5], dgrad = (int)r[6];
+  const int b0 = (int)r[7], nb = (int)descs[(d + 1) * 8 + 7] - b0;
+  const int kch = dgrad ? cout : cin, ocs = dgrad ? cin : cout;
+  const int nsteps = ((kch + SKC - 1) / SKC) * 2, colsP = ((ocs + 31) / 32) * 32;
+  const long long recs = (long long)nsteps * 9 * 2 * colsP;      // records per piece
+  for (long long i = (long long)(blockIdx.x - b0) * blockDim.x + threadIdx.x; i < recs; i += (long long)nb * blockDim.x) {
+    const int col = (int)(i % colsP);
+    long long t = i / colsP;
+    const int h = (int)(t % 2);
+    t /= 2;
+    const int tap = (int)(t % 9), step = (int)(t / 9);
+    unsigned hh[8], mm[8], ll[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kc = step * 16 + h * 8 + j;
+      float v = 0.f;
+      if (!dgrad) {
+        if (kc < cin && col < cout) v = w[((long long)col * cin_total + c_off + kc) * 9 + tap];
+      } else {
+        if (kc < cout && col < cin) v = w[((long long)kc * cin_total + c_off + col) * 9 + (8 - tap)];
+      }
+      split3(v, hh[j], mm[j], ll[j]);
+    }
+    u32x4 ph, pm, pl;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      ph[q] = hh[2 * q] | (hh[2 * q + 1] << 16);
+      pm[q] = mm[2 * q] | (mm[2 * q + 1] << 16);
+      pl[q] = ll[2 * q] | (ll[2 * q + 1] << 16);
+    }
+    wps[i] = ph;
+    wps[recs + i] = pm;
+    wps[2 * recs + i] = pl;
+  }
+}
+
+struct SCfg {
+  int th, tw, s, waves, npt, wm;
+};
+constexpr SCfg kS[] = {
+    {8, 16, 1, 4, 1, 1},   // 0: 128 px x 32 co
+    {8, 16, 1, 2, 2, 1},   // 1: 128 px x 32 co, 2 waves x 2 tiles
+    {8, 16, 1, 2, 2, 2},   // 2: 128 px x 64 co
+    {12, 18, 1, 4, 2, 1},  // 3: 216 px x 32 co
+    {12, 18, 1, 4, 2, 2},  // 4: 216 px x 64 co
+    {6, 9, 2, 4, 1, 1},    // 5: 2 x 54 px x 32 co
+    {6, 9, 2, 2, 2, 2},    // 6: 2 x 54 px x 64 co
+    {6, 9, 4, 4, 2, 1},    // 7: 4 x 54 px x 32 co
+    {6, 9, 4, 4, 2, 2},    // 8: 4 x 54 px x 64 co
+    {8, 24, 1, 3, 2, 1},   // 9: 192 px x 32 co
+    {8, 24, 1, 3, 2, 2},   // 10: 192 px x 64 co
+    {16, 24, 1, 4, 3, 1},  // 11: 384 px x 32 co
+};
+constexpr int kNumS = sizeof(kS) / sizeof(kS[0]);
+
+template <int I, bool DUAL>
+int launch_s(const SplitArgs& a0, hipStream_t st) {
+  constexpr SCfg c = kS[I];
+  SplitArgs a = a0;
+  a.tiles_x = cdiv(a.W, c.tw);
+  a.tiles_y = cdiv(a.H, c.th);
+  dim3 grid(a.tiles_x * a.tiles_y * cdiv(a.N, c.s), cdiv(a.Cout, 32 * c.wm));
+  conv3x3_split_kernel<c.th, c.tw, c.s, c.waves, c.npt, c.wm, DUAL><<<grid, c.waves * 64, 0, st>>>(a);
+  CM_CHECK_LAUNCH();
+  return 0;
+}
+
+template <bool DUAL>
+int dispatch_s(int cfg, const SplitArgs& a, hipStream_t st) {
+  switch (cfg) {
+    case 0: return launch_s<0, DUAL>(a, st);
+    case 1: return launch_s<1, DUAL>(a, st);
+    case 2: return launch_s<2, DUAL>(a, st);
+    case 3: return launch_s<3, DUAL>(a, st);
+    case 4: return launch_s<4, DUAL>(a, st);
+    case 5: return launch_s<5, DUAL>(a, st);
+    case 6: return launch_s<6, DUAL>(a, st);
+    case 7: return launch_s<7, DUAL>(a, st);
+    case 8: return launch_s<8, DUAL>(a, st);
+    case 9: return launch_s<9, DUAL>(a, st);
+    case 10: return launch_s<10, DUAL>(a, st);
+    case 11: return launch_s<11, DUAL>(a, st);
+    default: return -22;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int cm_conv3x3_split_num_configs(void) { return kNumS; }
+
+long long cm_conv3x3_split_packed_bytes(int k_channels, int out_channels) {
+  const long long nsteps = (long long)((k_channels + SKC - 1) / SKC) * 2;
+  const long long colsP = (long long)((out_channels + 31) / 32) * 32;
+  return 3 * nsteps * 9 * 2 * colsP * 16;
+}
+
+int cm_pack_conv3x3_split_batch(const void* descs_dev, int ndesc, int total_blocks, cm_stream stream) {
+  if (ndesc <= 0 || total_blocks <= 0) return -22;
+  pack_split_batch_kernel<<<total_blocks, 256, 0, (hipStream_t)stream>>>((const long long*)descs_dev, ndesc);
+  CM_CHECK_LAUNCH();
+  return 0;
+}
+
+int cm_conv3x3_split(const float* in0, long long st0, int c0, const float* in1, long long st1, int c1,
+                     const void* wps, const float* bias, const float* resid, long long st_resid, float* out,
+                     long long st_out, int n, int h, int w, int cout, int config, cm_stream stream) {
+  if (n <= 0 || h <= 0 || w <= 0 || cout <= 0 || c0 <= 0 || c1 < 0 || config < 0) return -22;
+  if (c1 > 0 && (c0 % SKC) != 0) return -22;   // a 32-channel stage must not straddle the two inputs
+  if (resid && st_resid != st_out) return -22;
+  SplitArgs a;
+  a.in0 = in0; a.in1 = in1; a.st0 = st0; a.st1 = st1; a.C0 = c0; a.C1 = c1;
+  a.wps = (const u32x4*)wps; a.bias = bias; a.resid = resid; a.out = out; a.sto = st_out;
+  a.N = n; a.H = h; a.W = w; a.Cout = cout;
+  a.CoutP = ((cout + 31) / 32) * 32;
+  a.nsteps = ((c0 + c1 + SKC - 1) / SKC) * 2;
+  a.tiles_x = a.tiles_y = 0;
+  return c1 > 0 ? dispatch_s<true>(config, a, (hipStream_t)stream) : dispatch_s<false>(config, a, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -45,6 +45,19 @@ def _conv_jobs(p: Params, need_input_grad: bool):
     return jobs
 
 
+USE_SPLIT = os.environ.get("CM_CONV_BF16X6", "1") != "0"
+
+
+class _Packs:
+    """Both operand forms of the packed 3x3 weights; ``conv(key, ...)`` lets the tuner choose the kernel family."""
+
+    def __init__(self, pk, pks):
+        self.pk, self.pks = pk, pks
+
+    def conv(self, key, x0, cout, **kw):
+        return ops.conv3x3(x0, self.pk[key], cout, wps=self.pks.get(key), **kw)
+
+
 class Plan:
     """Persistent per-model scratch: the packed-weight arena + its batched pack job table, and (for training) the
     tap-major weight-gradient staging arena + its batched unpack table.  One launch each per step for pack, zero
@@ -73,6 +86,24 @@ class Plan:
         rec.append([0, 0, 0, 0, 0, 0, 0, blk])
         self.pack_table = torch.tensor(rec, dtype=torch.int64).to(dev)
         self.pack_n, self.pack_blocks = len(jobs), blk
+        # bf16x6 operand forms of the same weights (the autotuner picks the kernel family per layer)
+        self.pks: Dict[str, Tensor] = {}
+        if USE_SPLIT:
+            ssz = []
+            for key, name, off, cin, dg in jobs:
+                w = p[name]
+                ssz.append(lib.cm_conv3x3_split_packed_bytes(w.shape[0] if dg else cin, cin if dg else w.shape[0]) // 4)
+            self.wps_arena = torch.empty(sum(ssz), device=dev, dtype=torch.float32)
+            rec, o, blk = [], 0, 0
+            for (key, name, off, cin, dg), sz in zip(jobs, ssz):
+                w = p[name]
+                self.pks[key] = self.wps_arena[o:o + sz]
+                rec.append([w.data_ptr(), self.pks[key].data_ptr(), w.shape[0], w.shape[1], off, cin, dg, blk])
+                blk += max(1, min(512, (sz // 12 + 255) // 256))
+                o += sz
+            rec.append([0, 0, 0, 0, 0, 0, 0, blk])
+            self.spack_table = torch.tensor(rec, dtype=torch.int64).to(dev)
+            self.spack_blocks = blk
         self.gw: Dict[str, Tensor] = {}
         if g is not None:
             names = [n for n in p if n.endswith("body.0.weight") or n.endswith("body.3.weight")]
@@ -98,9 +129,12 @@ class Plan:
 
     def pack(self):
         from ._lib import check, lib
-        check(lib.cm_pack_conv3x3_batch(self.pack_table.data_ptr(), self.pack_n, self.pack_blocks,
-                                        torch.cuda.current_stream().cuda_stream), "pack_batch")
-        return self.pk
+        st = torch.cuda.current_stream().cuda_stream
+        check(lib.cm_pack_conv3x3_batch(self.pack_table.data_ptr(), self.pack_n, self.pack_blocks, st), "pack_batch")
+        if self.pks:
+            check(lib.cm_pack_conv3x3_split_batch(self.spack_table.data_ptr(), self.pack_n, self.spack_blocks, st),
+                  "pack_split_batch")
+        return _Packs(self.pk, self.pks)
 
     def zero_staging(self):
         _zero_(self.g_arena)
@@ -132,9 +166,9 @@ def pack_weights(p: Params, need_input_grad: bool = False) -> Dict[str, Tensor]:
 # ------------------------------------------------------------------------------------------------- ConvBlock
 def _block_fwd(p: Params, pk, prefix: str, x0: Tensor, x1: Optional[Tensor], save: bool):
     co = p[prefix + "body.0.weight"].shape[0]
-    y1 = ops.conv3x3(x0, pk[prefix + "body.0.weight/f"], co, x1=x1)
+    y1 = pk.conv(prefix + "body.0.weight/f", x0, co, x1=x1)
     a1, st1, _ = ops.gn_silu_fwd(y1, p[prefix + "body.1.weight"], p[prefix + "body.1.bias"])
-    y2 = ops.conv3x3(a1, pk[prefix + "body.3.weight/f"], co)
+    y2 = pk.conv(prefix + "body.3.weight/f", a1, co)
     a2, st2, pooled = ops.gn_silu_fwd(y2, p[prefix + "body.4.weight"], p[prefix + "body.4.bias"], want_pooled=True)
     z, s = ops.se_excite_fwd(pooled, p[prefix + "se.fc.0.weight"], p[prefix + "se.fc.2.weight"])
     out, fmap, gate = ops.spatial_gate_fwd(a2, s, p[prefix + "spat.conv.weight"])
@@ -158,14 +192,14 @@ def _block_bwd(p: Params, pk, g: Params, gw: Params, ss: "_SideStream", prefix: 
                                 ctx.gate, dmap, ctx.fmap, cnt, ctx.s, dpool, g[prefix + "body.4.weight"],
                                 g[prefix + "body.4.bias"])
     ss.run(lambda: ops.wgrad3x3(ctx.a1, dy2, gw[prefix + "body.3.weight"]), ctx.a1, dy2)
-    da1 = ops.conv3x3(dy2, pk[prefix + "body.3.weight/d"], co)
+    da1 = pk.conv(prefix + "body.3.weight/d", dy2, co)
     dy1 = ops.gn_silu_bwd(ctx.y1, p[prefix + "body.1.weight"], p[prefix + "body.1.bias"], ctx.st1, da1,
                           g[prefix + "body.1.weight"], g[prefix + "body.1.bias"])
     ci = ctx.x0.shape[1] + (0 if ctx.x1 is None else ctx.x1.shape[1])
     ss.run(lambda: ops.wgrad3x3(ctx.x0, dy1, gw[prefix + "body.0.weight"], x1=ctx.x1), ctx.x0, ctx.x1, dy1)
     if not need_dx:
         return None
-    return ops.conv3x3(dy1, pk[prefix + "body.0.weight/d"], ci)
+    return pk.conv(prefix + "body.0.weight/d", dy1, ci)
 
 
 def _zeros(*shape, device) -> Tensor:
@@ -258,13 +292,13 @@ def forward(p: Params, pk, x_seq: Tensor, save: bool = True):
     wl, bl = p["convlstm.cell.conv.weight"], p["convlstm.cell.conv.bias"]
     ch = wl.shape[0] // 4
     h8, w8 = H // 8, W // 8
-    gx = ops.conv3x3(s4, pk["lstm.x/f"], 4 * ch, bias=bl).view(B, T, 4 * ch, h8, w8)
+    gx = pk.conv("lstm.x/f", s4, 4 * ch, bias=bl).view(B, T, 4 * ch, h8, w8)
     hprev = _zeros(B, T, ch, h8, w8, device=x.device)       # hprev[:, t] = h_{t-1}; slot 0 stays 0
     call = torch.empty(B, T, ch, h8, w8, device=x.device, dtype=torch.float32)
     bott = torch.empty(B, ch, h8, w8, device=x.device, dtype=torch.float32)
     for t in range(T):
         if t > 0:
-            ops.conv3x3(hprev[:, t], pk["lstm.h/f"], 4 * ch, resid=gx[:, t], out=gx[:, t])
+            pk.conv("lstm.h/f", hprev[:, t], 4 * ch, resid=gx[:, t], out=gx[:, t])
         ops.lstm_gates_fwd(gx[:, t], call[:, t - 1] if t > 0 else None, call[:, t],
                            hprev[:, t + 1] if t + 1 < T else bott)
 
@@ -323,7 +357,7 @@ def backward(p: Params, pk, g: Params, sv: Saved, dpred: Tensor, need_dx: bool =
         ops.lstm_gates_bwd(gx[:, t], call[:, t - 1] if t > 0 else None, call[:, t], dbott if t == T - 1 else None,
                            dhrec, dc, first=(t == T - 1))
         if t > 0:
-            dhrec = ops.conv3x3(gx[:, t], pk["lstm.h/d"], ch)
+            dhrec = pk.conv("lstm.h/d", gx[:, t], ch)
     dA = gx.view(B * T, 4 * ch, h8, w8)            # now holds d(pre-activations) for every (b, t)
     gl = gw["convlstm.cell.conv.weight"]
 
@@ -333,7 +367,7 @@ def backward(p: Params, pk, g: Params, sv: Saved, dpred: Tensor, need_dx: bool =
             ops.wgrad3x3(hprev.view(B * T, ch, h8, w8), dA, gl, c_off=cx)   # hprev[:, 0] == 0 contributes nothing
     ss.run(lstm_wgrads, sv.s4, dA, hprev)
     ops.channel_sum(dA, g["convlstm.cell.conv.bias"])
-    ds4 = ops.conv3x3(dA, pk["lstm.x/d"], cx)
+    ds4 = pk.conv("lstm.x/d", dA, cx)
 
     # ---- encoder ---------------------------------------------------------------------------------------
     dp3 = _block_bwd(p, pk, g, gw, ss, "enc4.conv.", c4, ds4)

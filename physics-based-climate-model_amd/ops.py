@@ -75,8 +75,14 @@ def pack_conv3x3(w, c_off=0, cin=None, dgrad=False):
     return wp
 
 
-def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1):
-    """out = conv3x3(cat(x0, x1), wp) + bias + resid.  x0/x1: [N,C,H,W] (sample stride may exceed C*H*W)."""
+SPLIT_BASE = 1 << 20   # tuned configuration ids >= SPLIT_BASE select the bf16x6 kernel (cm_conv3x3_split)
+
+
+def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1, wps=None):
+    """out = conv3x3(cat(x0, x1), wp) + bias + resid.  x0/x1: [N,C,H,W] (sample stride may exceed C*H*W).
+
+    ``wp`` is the fp32-MFMA operand (cm_pack_conv3x3); ``wps`` (optional) the bf16x6 operand of the same weight.
+    With config < 0 the autotuner times both kernel families on this call signature and keeps the faster one."""
     n, c0, h, w = x0.shape
     c1 = 0 if x1 is None else x1.shape[1]
     if out is None:
@@ -89,15 +95,55 @@ def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1):
         def launch(cfg, _scratch=[None]):
             if _scratch[0] is None:
                 _scratch[0] = torch.empty(n, cout, h, w, device=x0.device, dtype=torch.float32)
+            if cfg >= SPLIT_BASE:
+                return lib.cm_conv3x3_split(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(wps), _p(bias), None, 0,
+                                            _p(_scratch[0]), _scratch[0].stride(0), n, h, w, cout, cfg - SPLIT_BASE,
+                                            _stream())
             return lib.cm_conv3x3(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(wp), _p(bias), None, 0,
                                   _p(_scratch[0]), _scratch[0].stride(0), n, h, w, cout, cfg, _stream())
         nchunks = (c0 + c1 + 7) // 8
         splits = [1] + [k for k in (2, 4, 8) if nchunks >= 4 * k and not (resid is not None and resid.data_ptr() == out.data_ptr())]
         cands = [c + ((k if k > 1 else 0) << 8) for c in range(lib.cm_conv3x3_num_configs()) for k in splits]
-        config = _pick(("conv3x3", n, h, w, c0, c1, cout, len(splits)), cands, launch, -1)
+        use_split = wps is not None and (c1 == 0 or c0 % 32 == 0)
+        if use_split:
+            cands += [SPLIT_BASE + c for c in range(lib.cm_conv3x3_split_num_configs())]
+        config = _pick(("conv3x3", n, h, w, c0, c1, cout, len(splits), use_split), cands, launch, -1)
+    if config >= SPLIT_BASE:
+        check(lib.cm_conv3x3_split(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(wps), _p(bias), _p(resid),
+                                   0 if resid is None else resid.stride(0), _p(out), out.stride(0), n, h, w, cout,
+                                   config - SPLIT_BASE, _stream()), "conv3x3_split")
+        return out
     check(lib.cm_conv3x3(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(wp), _p(bias),
                          _p(resid), 0 if resid is None else resid.stride(0), _p(out), out.stride(0), n, h, w, cout,
                          config, _stream()), "conv3x3")
+    return out
+
+
+def pack_conv3x3_split(w, c_off=0, cin=None, dgrad=False):
+    """bf16x6 operand form of a 3x3 weight (single-job use of the batched packer; the engine batches all jobs)."""
+    cout, cin_total = w.shape[0], w.shape[1]
+    cin = cin_total - c_off if cin is None else cin
+    nbytes = lib.cm_conv3x3_split_packed_bytes(cout if dgrad else cin, cin if dgrad else cout)
+    wps = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
+    blocks = max(1, min(512, nbytes // 48 // 256 + 1))
+    table = torch.tensor([[w.data_ptr(), wps.data_ptr(), cout, cin_total, c_off, cin, int(dgrad), 0],
+                          [0, 0, 0, 0, 0, 0, 0, blocks]], dtype=torch.int64).to(w.device)
+    check(lib.cm_pack_conv3x3_split_batch(_p_any(table), 1, blocks, _stream()), "pack_split")
+    return wps
+
+
+def _p_any(t):
+    return t.data_ptr()
+
+
+def conv3x3_split(x0, wps, cout, x1=None, bias=None, resid=None, out=None, config=0):
+    n, c0, h, w = x0.shape
+    c1 = 0 if x1 is None else x1.shape[1]
+    if out is None:
+        out = torch.empty(n, cout, h, w, device=x0.device, dtype=torch.float32)
+    check(lib.cm_conv3x3_split(_p(x0), x0.stride(0), c0, _p(x1), 0 if x1 is None else x1.stride(0), c1, _p(wps),
+                               _p(bias), _p(resid), 0 if resid is None else resid.stride(0), _p(out), out.stride(0),
+                               n, h, w, cout, config, _stream()), "conv3x3_split")
     return out
 
 

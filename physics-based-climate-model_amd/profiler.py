@@ -38,6 +38,7 @@ def _lstm_bwd_bytes(a):    # (gates, sg, c_prev, scp, c_cur, scc, dh_a, sa, dh_b
 
 MODELS = {
     "cm_conv3x3": (_conv_flops, _conv_bytes),
+    "cm_conv3x3_split": (_conv_flops, _conv_bytes),     # same argument positions; ALGORITHMIC flops (x6 are executed)
     "cm_wgrad3x3": (_wgrad_flops, _wgrad_bytes),
     "cm_lstm_gates_fwd": (None, _lstm_fwd_bytes),
     "cm_lstm_gates_bwd": (None, _lstm_bwd_bytes),

@@ -352,7 +352,7 @@ def test_autotune_is_cached_and_correct(ops):
     x = rnd(4, 16, 12, 18, seed=70); wt = rnd(32, 16, 3, 3, seed=71, scale=0.1)
     wp = ops.pack_conv3x3(dev(wt))
     y = ops.conv3x3(dev(x), wp, 32)
-    key = ("conv3x3", 4, 12, 18, 16, 0, 32, 1)
+    key = ("conv3x3", 4, 12, 18, 16, 0, 32, 1, False)
     assert key in ops.tuned_table()
     assert rel_l2(y, F.conv2d(x.double(), wt.double(), padding=1)) < TOL
 
@@ -372,3 +372,29 @@ def test_conv3x3_split_k(ops):
     rc = lib.cm_conv3x3(dev(x).data_ptr(), ci * h * w, ci, None, 0, 0, wp.data_ptr(), None, buf.data_ptr(), co * h * w,
                         buf.data_ptr(), co * h * w, n, h, w, co, 7 + (2 << 8), None)
     assert rc == -22          # split-K with an in-place residual is refused
+
+
+@pytest.mark.parametrize("case", [(3, 5, 0, 16, 16, 24), (2, 32, 32, 32, 12, 18), (5, 40, 0, 70, 10, 14),
+                                  (7, 64, 0, 64, 6, 9), (2, 32, 0, 8, 48, 72)])
+def test_conv3x3_split_bf16x6(ops, case):
+    """bf16x6 convolution (three bf16 pieces per operand, six MFMAs per k-step): fp32-equivalent accuracy."""
+    from climate_amd._lib import lib
+    n, c0, c1, cout, h, w = case
+    x0 = rnd(n, c0, h, w, seed=90)
+    x1 = rnd(n, c1, h, w, seed=91) if c1 else None
+    wt = rnd(cout, c0 + c1, 3, 3, seed=92, scale=(9 * (c0 + c1)) ** -0.5)
+    b = rnd(cout, seed=93); r = rnd(n, cout, h, w, seed=94)
+    xin = x0 if x1 is None else torch.cat([x0, x1], 1)
+    ref = F.conv2d(xin.double(), wt.double(), b.double(), padding=1) + r.double()
+    wps = ops.pack_conv3x3_split(dev(wt))
+    for cfg in range(lib.cm_conv3x3_split_num_configs()):
+        y = ops.conv3x3_split(dev(x0), wps, cout, x1=None if x1 is None else dev(x1), bias=dev(b), resid=dev(r),
+                              config=cfg)
+        assert rel_l2(y, ref) < 2e-6, f"config {cfg}: {rel_l2(y, ref)}"
+    # data gradient form
+    wpd = ops.pack_conv3x3_split(dev(wt), dgrad=True)
+    dy = rnd(n, cout, h, w, seed=95)
+    xd = torch.zeros_like(xin, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xd, wt.double(), padding=1).backward(dy.double())
+    dx = ops.conv3x3_split(dev(dy), wpd, c0 + c1, config=0)
+    assert rel_l2(dx, xd.grad) < 2e-6

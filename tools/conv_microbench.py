@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--B", type=int, default=32)
     ap.add_argument("--T", type=int, default=6)
     ap.add_argument("--what", default="both")
+    ap.add_argument("--split", action="store_true", help="also time the bf16x6 kernel on the forward shapes")
     args = ap.parse_args()
     st = torch.cuda.current_stream().cuda_stream
     tot = {"conv": 0.0, "dgrad": 0.0, "wgrad": 0.0}
@@ -67,6 +68,20 @@ def main():
             tot["conv"] += res[0][0]
             print(f"conv  {name:8s} N={n:3d} {ci:3d}->{co:3d} @{h}x{w}: best cfg {res[0][1]:2d} {res[0][0]:7.1f} us "
                   f"{flops / res[0][0] / 1e6:6.1f} TF | " + " ".join(f"{c}:{t:.0f}" for t, c in res[1:6]))
+            if args.split:
+                wps = ops.pack_conv3x3_split(wt)
+                res = []
+                for cfg in range(lib.cm_conv3x3_split_num_configs()):
+                    try:
+                        t = timeit(lambda: ops.conv3x3_split(x0, wps, co, x1=x1, out=out, config=cfg))
+                    except RuntimeError:
+                        continue
+                    res.append((t, cfg))
+                res.sort()
+                tot.setdefault("conv_split", 0.0)
+                tot["conv_split"] += res[0][0]
+                print(f"split {name:8s} N={n:3d} {ci:3d}->{co:3d} @{h}x{w}: best cfg {res[0][1]:2d} {res[0][0]:7.1f} us "
+                      f"{flops / res[0][0] / 1e6:6.1f} TF | " + " ".join(f"{c}:{t:.0f}" for t, c in res[1:6]))
             if name != "enc1.c1":
                 wpd = ops.pack_conv3x3(wt, dgrad=True)
                 outd = torch.empty(n, ci, h, w, device="cuda")
