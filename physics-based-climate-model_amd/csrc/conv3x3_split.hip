@@ -24,18 +24,20 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SKC = 32;   // input channels per LDS stage (two 16-channel MFMA k-steps per tap)
 
-__device__ __forceinline__ unsigned bf16_rne(float f) {   // round-to-nearest-even bf16 bits (finite inputs)
-  const unsigned u = __float_as_uint(f);
-  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
-// split v into three bf16 pieces; returns them as 16-bit values
-__device__ __forceinline__ void split3(float v, unsigned& h, unsigned& m, unsigned& l) {
-  h = bf16_rne(v);
-  const float r1 = v - __uint_as_float(h << 16);
-  m = bf16_rne(r1);
-  const float r2 = r1 - __uint_as_float(m << 16);
-  l = bf16_rne(r2);
+// Split two floats into three packed bf16 pairs (element 0 in the low half).  The vector convert lowers to
+// v_cvt_pk_bf16_f32 (round-to-nearest-even); each residual v - float(piece) is exact in fp32.
+__device__ __forceinline__ void split3_pair(float v0, float v1, unsigned& ph, unsigned& pm, unsigned& pl) {
+  f32x2_t v = {v0, v1};
+  ph = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+  f32x2_t hf = {__uint_as_float(ph << 16), __uint_as_float(ph & 0xffff0000u)};
+  const f32x2_t r1 = v - hf;
+  pm = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2_t));
+  f32x2_t mf = {__uint_as_float(pm << 16), __uint_as_float(pm & 0xffff0000u)};
+  const f32x2_t r2 = r1 - mf;
+  pl = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2_t));
 }
 
 struct SplitArgs {
@@ -136,20 +138,16 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_split_kernel(SplitArgs a) 
     for (int i = 0; i < NI; ++i) {
       const int e = tid + i * THREADS;
       const int oct = e / PH, pix = e % PH;
-      unsigned hh[8], mm[8], ll[8];
+      u32x4 ph, pm, pl;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const bool ok = goff0[i] >= 0 && (oct * 8 + j) < cvalid_pending;
-        split3(ok ? xr[i][j] : 0.f, hh[j], mm[j], ll[j]);
+      for (int q = 0; q < 4; ++q) {
+        const bool ok0 = goff0[i] >= 0 && (oct * 8 + 2 * q) < cvalid_pending;
+        const bool ok1 = goff0[i] >= 0 && (oct * 8 + 2 * q + 1) < cvalid_pending;
+        unsigned a_, b_, c_;
+        split3_pair(ok0 ? xr[i][2 * q] : 0.f, ok1 ? xr[i][2 * q + 1] : 0.f, a_, b_, c_);
+        ph[q] = a_; pm[q] = b_; pl[q] = c_;
       }
       if (e < ITEMS) {
-        u32x4 ph, pm, pl;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          ph[q] = hh[2 * q] | (hh[2 * q + 1] << 16);
-          pm[q] = mm[2 * q] | (mm[2 * q + 1] << 16);
-          pl[q] = ll[2 * q] | (ll[2 * q + 1] << 16);
-        }
         Xl[(0 * 4 + oct) * PH + pix] = ph;
         Xl[(1 * 4 + oct) * PH + pix] = pm;
         Xl[(2 * 4 + oct) * PH + pix] = pl;
@@ -299,7 +297,7 @@ __global__ void pack_split_batch_kernel(const long long* __restrict__ descs, int
     const int h = (int)(t % 2);
     t /= 2;
     const int tap = (int)(t % 9), step = (int)(t / 9);
-    unsigned hh[8], mm[8], ll[8];
+    float vv[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int kc = step * 16 + h * 8 + j;
@@ -309,14 +307,14 @@ __global__ void pack_split_batch_kernel(const long long* __restrict__ descs, int
       } else {
         if (kc < cout && col < cin) v = w[((long long)kc * cin_total + c_off + col) * 9 + (8 - tap)];
       }
-      split3(v, hh[j], mm[j], ll[j]);
+      vv[j] = v;
     }
     u32x4 ph, pm, pl;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      ph[q] = hh[2 * q] | (hh[2 * q + 1] << 16);
-      pm[q] = mm[2 * q] | (mm[2 * q + 1] << 16);
-      pl[q] = ll[2 * q] | (ll[2 * q + 1] << 16);
+      unsigned a_, b_, c_;
+      split3_pair(vv[2 * q], vv[2 * q + 1], a_, b_, c_);
+      ph[q] = a_; pm[q] = b_; pl[q] = c_;
     }
     wps[i] = ph;
     wps[recs + i] = pm;
@@ -340,6 +338,14 @@ constexpr SCfg kS[] = {
     {8, 24, 1, 3, 2, 1},   // 9: 192 px x 32 co
     {8, 24, 1, 3, 2, 2},   // 10: 192 px x 64 co
     {16, 24, 1, 4, 3, 1},  // 11: 384 px x 32 co
+    {8, 16, 1, 4, 1, 2},   // 12: 128 px x 64 co
+    {16, 16, 1, 8, 1, 1},  // 13: 256 px x 32 co, 8 waves
+    {16, 16, 1, 8, 1, 2},  // 14: 256 px x 64 co, 8 waves
+    {12, 18, 1, 8, 1, 2},  // 15: 216 px x 64 co, 8 waves
+    {6, 9, 4, 8, 1, 2},    // 16: 4 x 54 px x 64 co, 8 waves
+    {6, 9, 4, 8, 1, 1},    // 17: 4 x 54 px x 32 co, 8 waves
+    {12, 18, 1, 8, 1, 1},  // 18: 216 px x 32 co, 8 waves
+    {16, 24, 1, 6, 2, 2},  // 19: 384 px x 64 co, 6 waves
 };
 constexpr int kNumS = sizeof(kS) / sizeof(kS[0]);
 
@@ -370,6 +376,14 @@ int dispatch_s(int cfg, const SplitArgs& a, hipStream_t st) {
     case 9: return launch_s<9, DUAL>(a, st);
     case 10: return launch_s<10, DUAL>(a, st);
     case 11: return launch_s<11, DUAL>(a, st);
+    case 12: return launch_s<12, DUAL>(a, st);
+    case 13: return launch_s<13, DUAL>(a, st);
+    case 14: return launch_s<14, DUAL>(a, st);
+    case 15: return launch_s<15, DUAL>(a, st);
+    case 16: return launch_s<16, DUAL>(a, st);
+    case 17: return launch_s<17, DUAL>(a, st);
+    case 18: return launch_s<18, DUAL>(a, st);
+    case 19: return launch_s<19, DUAL>(a, st);
     default: return -22;
   }
 }
