@@ -51,7 +51,7 @@ int cm_conv3x3(const float* in0, long long st0, int c0, const float* in1, long l
  * Same contract as cm_conv3x3 (same reference call sites), operands split into three bf16 pieces each, six bf16
  * MFMAs per 16-deep k-step, fp32 accumulation.  wps comes from cm_pack_conv3x3_split_batch (descriptor records as
  * cm_pack_conv3x3_batch, with the wp field pointing at cm_conv3x3_split_packed_bytes() bytes).  When in1 is given,
- * c0 must be a multiple of 32.  config in [0, cm_conv3x3_split_num_configs()).                                    */
+ * c0 must be a multiple of 16.  config in [0, cm_conv3x3_split_num_configs()).                                    */
 int cm_conv3x3_split_num_configs(void);
 long long cm_conv3x3_split_packed_bytes(int k_channels, int out_channels);
 int cm_pack_conv3x3_split_batch(const void* descs_dev, int ndesc, int total_blocks, cm_stream stream);

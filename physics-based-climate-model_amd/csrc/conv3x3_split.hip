@@ -12,8 +12,10 @@
 //   * K runs over 16 input channels of one tap per MFMA; a lane's fragment is 8 consecutive channels (16 bytes);
 //   * the haloed input tile is converted on the way into LDS: a thread loads 8 channels of one pixel (8 coalesced
 //     dword loads), splits them, and writes three 16-byte records Xl[piece][channel-octet][pixel];
-//   * weight fragments are pre-split by cm_pack_conv3x3_split into [piece][16-channel step][tap][octet][cout][8]
-//     and read straight from global memory (L1/L2 resident, one k-step ahead, ping-pong registers), no LDS.
+//   * weight fragments are pre-split by cm_pack_conv3x3_split into [piece][16-channel step][tap][octet][cout][8];
+//     the slab of one 16-channel step ([3][9][2][32*WM] 16-byte records) is staged in LDS next to the input tile and
+//     shared by the workgroup's waves (reading the fragments straight from L2 in every wave cost ~60 % of a CU's L2
+//     bandwidth and 24-48 VGPRs of ping-pong registers).
 #include "common.h"
 #include "../../include/climate_hip.h"
 
@@ -22,7 +24,7 @@ namespace {
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int SKC = 32;   // input channels per LDS stage (two 16-channel MFMA k-steps per tap)
+constexpr int SKC = 16;   // input channels per LDS stage = one 16-deep MFMA k-step per tap
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -50,7 +52,7 @@ struct SplitArgs {
   const float* resid;
   float* out;
   long long sto;
-  int N, H, W, Cout, CoutP, nsteps, tiles_x, tiles_y;   // nsteps = 16-channel k-steps = 2 * nchunks
+  int N, H, W, Cout, CoutP, nsteps, tiles_x, tiles_y;   // nsteps = 16-channel k-steps (= LDS stages)
 };
 
 template <int TH, int TW, int S, int WAVES, int NPT, int WM, bool DUAL>
@@ -59,13 +61,16 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_split_kernel(SplitArgs a) 
   constexpr int PITCH = TW + 2;
   constexpr int SS = (TH + 2) * PITCH;
   constexpr int PH = S * SS;                     // haloed pixels per stage
-  constexpr int ITEMS = PH * 4;                  // (pixel, channel octet) records per 32-channel stage
+  constexpr int ITEMS = PH * 2;                  // (pixel, channel octet) records per 16-channel stage
   constexpr int NI = (ITEMS + THREADS - 1) / THREADS;
   constexpr int BCO = 32 * WM;
+  constexpr int WREC = 3 * 9 * 2 * BCO;          // weight records (16 B) per stage
+  constexpr int NWR = (WREC + THREADS - 1) / THREADS;
   constexpr int PIX = S * TH * TW;
   static_assert(WAVES * NPT * 32 >= PIX, "block does not cover its pixel set");
 
-  __shared__ u32x4 Xl[3 * 4 * PH];               // [piece][octet][pixel]
+  __shared__ u32x4 Xl[3 * 2 * PH];               // [piece][octet][pixel]
+  __shared__ u32x4 Wl[WREC];                     // [piece][tap][octet][cout]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -85,7 +90,6 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_split_kernel(SplitArgs a) 
   const int x0 = tx * TW, y0 = ty * TH, n0 = g * S;
   const int co0 = blockIdx.y * BCO;
   const int HW = a.H * a.W;
-  const int nchunks = nsteps / 2;
 
   // ---- stage-invariant staging offsets: item -> (octet, pixel) ----
   int goff0[NI];
@@ -104,7 +108,9 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_split_kernel(SplitArgs a) 
   }
 
   float xr[NI][8];
+  u32x4 wr[NWR];
   int cvalid_pending = 0;
+  const long long piece_stride = (long long)nsteps * 9 * 2 * a_CoutP;   // records per piece in the packed weights
 
   auto load_chunk = [&](int chunk) {
     const int ch0 = chunk * SKC;
@@ -132,6 +138,15 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_split_kernel(SplitArgs a) 
         xr[i][j] = src[ok ? off + c * HW : 0];          // clamped address; zero-select happens at store time
       }
     }
+    // weight slab of this step: record r = ((piece*9 + tap)*2 + half)*BCO + col
+    const u32x4* wsrc = a_wps + (long long)chunk * 9 * 2 * a_CoutP + co0;
+#pragma unroll
+    for (int i = 0; i < NWR; ++i) {
+      const int r = min(tid + i * THREADS, WREC - 1);
+      const int col = r % BCO, t2 = r / BCO;            // t2 = (piece*9 + tap)*2 + half
+      const int pc = t2 / 18, th = t2 % 18;
+      wr[i] = wsrc[pc * piece_stride + (long long)th * a_CoutP + col];
+    }
   };
   auto store_chunk = [&]() {
 #pragma unroll
@@ -148,10 +163,15 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_split_kernel(SplitArgs a) 
         ph[q] = a_; pm[q] = b_; pl[q] = c_;
       }
       if (e < ITEMS) {
-        Xl[(0 * 4 + oct) * PH + pix] = ph;
-        Xl[(1 * 4 + oct) * PH + pix] = pm;
-        Xl[(2 * 4 + oct) * PH + pix] = pl;
+        Xl[(0 * 2 + oct) * PH + pix] = ph;
+        Xl[(1 * 2 + oct) * PH + pix] = pm;
+        Xl[(2 * 2 + oct) * PH + pix] = pl;
       }
+    }
+#pragma unroll
+    for (int i = 0; i < NWR; ++i) {
+      const int r = tid + i * THREADS;
+      if (r < WREC) Wl[r] = wr[i];
     }
   };
 
@@ -166,7 +186,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_split_kernel(SplitArgs a) 
     const int qq = inq ? q : 0;
     const int s = qq / (TH * TW), rem = qq % (TH * TW);
     const int py = rem / TW, px = rem % TW;
-    xbase[p] = half * PH + s * SS + py * PITCH + px;      // octet = 2*sub + half -> +half*PH records
+    xbase[p] = half * PH + s * SS + py * PITCH + px;      // octet = half -> +half*PH records
     const int n = n0 + s, gy = y0 + py, gx = x0 + px;
     pvalid[p] = inq && n < a.N && gy < a.H && gx < a.W;
     obase[p] = (long long)n * a.sto + (long long)gy * a.W + gx;
@@ -180,42 +200,27 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_split_kernel(SplitArgs a) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][p][r] = 0.f;
 
-  // A fragments: record index = ((piece*nsteps*9 + T)*2 + half)*CoutP + cout with T = step*9 + tap (linear over K)
-  const long long piece_stride = (long long)nsteps * 9 * 2 * a_CoutP;
-  const u32x4* wlane = a_wps + (long long)half * a_CoutP + co0 + l31;
-  auto load_a = [&](u32x4 (&dst)[3][WM], int T) {
-#pragma unroll
-    for (int pc = 0; pc < 3; ++pc)
-#pragma unroll
-      for (int m = 0; m < WM; ++m) dst[pc][m] = wlane[pc * piece_stride + (long long)T * 2 * a_CoutP + m * 32];
-  };
+  const int wlane = half * BCO + l31;
 
-  u32x4 afr[2][3][WM];
-  load_a(afr[0], 0);
   load_chunk(0);
-  const int total_T = nsteps * 9;
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
+  for (int chunk = 0; chunk < nsteps; ++chunk) {
     store_chunk();
     __syncthreads();
-    if (chunk + 1 < nchunks) load_chunk(chunk + 1);
+    if (chunk + 1 < nsteps) load_chunk(chunk + 1);
 #pragma unroll
-    for (int st = 0; st < 18; ++st) {               // 2 sixteen-channel sub-steps x 9 taps; 18 is even: the
-      const int sub = st / 9, tap = st % 9;         // ping-pong parity is the same in every chunk
-      const int T = chunk * 18 + st;
-      if (T + 1 < total_T) load_a(afr[(st + 1) & 1], T + 1);
+    for (int tap = 0; tap < 9; ++tap) {
       bf16x8 bf[3][NPT];
 #pragma unroll
       for (int pc = 0; pc < 3; ++pc)
 #pragma unroll
-        for (int p = 0; p < NPT; ++p) {
-          const u32x4 v = Xl[(pc * 4 + sub * 2) * PH + xbase[p] + (tap / 3) * PITCH + (tap % 3)];
-          bf[pc][p] = __builtin_bit_cast(bf16x8, v);
-        }
+        for (int p = 0; p < NPT; ++p)
+          bf[pc][p] = __builtin_bit_cast(bf16x8, Xl[(pc * 2) * PH + xbase[p] + (tap / 3) * PITCH + (tap % 3)]);
 #pragma unroll
       for (int m = 0; m < WM; ++m) {
         bf16x8 af[3];
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) af[pc] = __builtin_bit_cast(bf16x8, afr[st & 1][pc][m]);
+        for (int pc = 0; pc < 3; ++pc)
+          af[pc] = __builtin_bit_cast(bf16x8, Wl[(pc * 9 + tap) * 2 * BCO + wlane + m * 32]);
 #pragma unroll
         for (int p = 0; p < NPT; ++p) {
           // smallest terms first
@@ -289,7 +294,7 @@ __global__ void pack_split_batch_kernel(const long long* __restrict__ descs, int
   const int cout = (int)r[2], cin_total = (int)r[3], c_off = (int)r[4], cin = (int)r[5], dgrad = (int)r[6];
   const int b0 = (int)r[7], nb = (int)descs[(d + 1) * 8 + 7] - b0;
   const int kch = dgrad ? cout : cin, ocs = dgrad ? cin : cout;
-  const int nsteps = ((kch + SKC - 1) / SKC) * 2, colsP = ((ocs + 31) / 32) * 32;
+  const int nsteps = (kch + SKC - 1) / SKC, colsP = ((ocs + 31) / 32) * 32;
   const long long recs = (long long)nsteps * 9 * 2 * colsP;      // records per piece
   for (long long i = (long long)(blockIdx.x - b0) * blockDim.x + threadIdx.x; i < recs; i += (long long)nb * blockDim.x) {
     const int col = (int)(i % colsP);
@@ -395,7 +400,7 @@ extern "C" {
 int cm_conv3x3_split_num_configs(void) { return kNumS; }
 
 long long cm_conv3x3_split_packed_bytes(int k_channels, int out_channels) {
-  const long long nsteps = (long long)((k_channels + SKC - 1) / SKC) * 2;
+  const long long nsteps = (long long)((k_channels + SKC - 1) / SKC);
   const long long colsP = (long long)((out_channels + 31) / 32) * 32;
   return 3 * nsteps * 9 * 2 * colsP * 16;
 }
@@ -411,14 +416,14 @@ int cm_conv3x3_split(const float* in0, long long st0, int c0, const float* in1, 
                      const void* wps, const float* bias, const float* resid, long long st_resid, float* out,
                      long long st_out, int n, int h, int w, int cout, int config, cm_stream stream) {
   if (n <= 0 || h <= 0 || w <= 0 || cout <= 0 || c0 <= 0 || c1 < 0 || config < 0) return -22;
-  if (c1 > 0 && (c0 % SKC) != 0) return -22;   // a 32-channel stage must not straddle the two inputs
+  if (c1 > 0 && (c0 % SKC) != 0) return -22;   // a 16-channel stage must not straddle the two inputs
   if (resid && st_resid != st_out) return -22;
   SplitArgs a;
   a.in0 = in0; a.in1 = in1; a.st0 = st0; a.st1 = st1; a.C0 = c0; a.C1 = c1;
   a.wps = (const u32x4*)wps; a.bias = bias; a.resid = resid; a.out = out; a.sto = st_out;
   a.N = n; a.H = h; a.W = w; a.Cout = cout;
   a.CoutP = ((cout + 31) / 32) * 32;
-  a.nsteps = ((c0 + c1 + SKC - 1) / SKC) * 2;
+  a.nsteps = (c0 + c1 + SKC - 1) / SKC;
   a.tiles_x = a.tiles_y = 0;
   return c1 > 0 ? dispatch_s<true>(config, a, (hipStream_t)stream) : dispatch_s<false>(config, a, (hipStream_t)stream);
 }

@@ -104,7 +104,7 @@ def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1, w
         nchunks = (c0 + c1 + 7) // 8
         splits = [1] + [k for k in (2, 4, 8) if nchunks >= 4 * k and not (resid is not None and resid.data_ptr() == out.data_ptr())]
         cands = [c + ((k if k > 1 else 0) << 8) for c in range(lib.cm_conv3x3_num_configs()) for k in splits]
-        use_split = wps is not None and (c1 == 0 or c0 % 32 == 0)
+        use_split = wps is not None and (c1 == 0 or c0 % 16 == 0)
         if use_split:
             cands += [SPLIT_BASE + c for c in range(lib.cm_conv3x3_split_num_configs())]
         config = _pick(("conv3x3", n, h, w, c0, c1, cout, len(splits), use_split), cands, launch, -1)
