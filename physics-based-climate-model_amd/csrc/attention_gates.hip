@@ -141,45 +141,82 @@ __global__ __launch_bounds__(256) void spatial_stats_kernel(const float* __restr
   }
 }
 
-__device__ __forceinline__ float conv7_at(const float* __restrict__ mp, const float* __restrict__ w7, int y, int x,
-                                          int H, int W) {
-  float a = 0.f;
-  const int HW = H * W;
-#pragma unroll
-  for (int ch = 0; ch < 2; ++ch)
-    for (int dy = 0; dy < 7; ++dy) {
-      const int yy = y + dy - 3;
-      if (yy < 0 || yy >= H) continue;
-#pragma unroll
-      for (int dx = 0; dx < 7; ++dx) {
-        const int xx = x + dx - 3;
-        if (xx >= 0 && xx < W) a += w7[ch * 49 + dy * 7 + dx] * mp[ch * HW + yy * W + xx];
-      }
-    }
-  return a;
-}
-
-// gate = sigmoid(conv7x7(map)); out = a2 * s * gate.  grid = (pixel blocks, N, channel splits)
-__global__ void spatial_apply_kernel(const float* __restrict__ a2, const float* __restrict__ s,
-                                     const float* __restrict__ map, const float* __restrict__ w7,
-                                     float* __restrict__ gate, float* __restrict__ out, int C, int H, int W,
-                                     int c_per_split) {
+// gate = sigmoid(conv7x7(map)); out = a2 * s * gate.
+// Workgroup = (row band, sample, channel split): the band's map rows (+-3, zero padded) are staged in LDS, the gate of
+// the band's pixels is computed once into LDS (XB adjacent pixels per thread share their 7x(XB+6) window reads), then
+// the band -- a contiguous run of BAND*W floats per channel -- is streamed with VEC-wide accesses.
+constexpr int GATE_BAND = 8;
+template <int VEC>
+__global__ __launch_bounds__(256) void spatial_apply_kernel(const float* __restrict__ a2, const float* __restrict__ s,
+                                                             const float* __restrict__ map,
+                                                             const float* __restrict__ w7, float* __restrict__ gate,
+                                                             float* __restrict__ out, int C, int H, int W,
+                                                             int c_per_split) {
+  constexpr int BAND = GATE_BAND, XB = 4;
+  extern __shared__ float sh[];
+  const int PW = W + 6 + XB;                   // row pitch of the padded map tile (room for the XB overshoot)
+  float* msh = sh;                             // [2][BAND+6][PW]
+  float* gsh = sh + 2 * (BAND + 6) * PW;       // [BAND*W] gate of the band
   __shared__ float wsh[98];
-  if (threadIdx.x < 98) wsh[threadIdx.x] = w7[threadIdx.x];
+  const int tid = threadIdx.x;
+  const int HW = H * W, n = blockIdx.y, y0 = blockIdx.x * BAND;
+  const int rows = min(BAND, H - y0), npx = rows * W;
+  if (tid < 98) wsh[tid] = w7[tid];
+  const int plane = (BAND + 6) * PW;
+  for (int i = tid; i < 2 * plane; i += 256) {
+    const int ch = i / plane, r = (i % plane) / PW, cpos = (i % plane) % PW;
+    const int yy = y0 - 3 + r, xx = cpos - 3;
+    float v = 0.f;
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = map[((long long)n * 2 + ch) * HW + yy * W + xx];
+    msh[i] = v;
+  }
   __syncthreads();
-  const int HW = H * W;
-  const int n = blockIdx.y;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= HW) return;
-  const float gpre = conv7_at(map + (long long)n * 2 * HW, wsh, p / W, p % W, H, W);
-  const float g = sigmoid_acc(gpre);
-  if (blockIdx.z == 0) gate[(long long)n * HW + p] = g;
+  const int xblocks = (W + XB - 1) / XB;
+  for (int i = tid; i < rows * xblocks; i += 256) {
+    const int r = i / xblocks, x0 = (i % xblocks) * XB;
+    float acc[XB];
+#pragma unroll
+    for (int j = 0; j < XB; ++j) acc[j] = 0.f;
+    // fixed accumulation order: ch, dy, dx (out-of-image taps contribute exact zeros from the padded tile)
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch)
+      for (int dy = 0; dy < 7; ++dy) {
+        const float* mr = msh + ch * plane + (r + dy) * PW + x0;
+        float win[XB + 6];
+#pragma unroll
+        for (int q = 0; q < XB + 6; ++q) win[q] = mr[q];
+#pragma unroll
+        for (int dx = 0; dx < 7; ++dx) {
+          const float wv = wsh[ch * 49 + dy * 7 + dx];
+#pragma unroll
+          for (int j = 0; j < XB; ++j) acc[j] += wv * win[j + dx];
+        }
+      }
+#pragma unroll
+    for (int j = 0; j < XB; ++j)
+      if (x0 + j < W) gsh[r * W + x0 + j] = sigmoid_acc(acc[j]);
+  }
+  __syncthreads();
+  if (blockIdx.z == 0)
+    for (int i = tid; i < npx; i += 256) gate[(long long)n * HW + y0 * W + i] = gsh[i];
   const int c0 = blockIdx.z * c_per_split;
-  const int c1 = min(C, c0 + c_per_split);
+  const int nc = min(C, c0 + c_per_split) - c0;
+  const int nv = npx / VEC;                    // host guarantees npx % VEC == 0 and aligned bases
   const float* sp = s + (long long)n * C;
-  for (int c = c0; c < c1; ++c) {
-    const long long i = ((long long)n * C + c) * HW + p;
-    out[i] = (a2[i] * sp[c]) * g;
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  for (int i = tid; i < nc * nv; i += 256) {
+    const int c = c0 + i / nv, v = i % nv;
+    const long long off = ((long long)n * C + c) * HW + y0 * W + v * VEC;
+    const float sc = sp[c];
+    if constexpr (VEC == 1) {
+      out[off] = (a2[off] * sc) * gsh[v];
+    } else {
+      const vec_t av = *reinterpret_cast<const vec_t*>(a2 + off);
+      vec_t ov;
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) ov[q] = (av[q] * sc) * gsh[v * VEC + q];
+      *reinterpret_cast<vec_t*>(out + off) = ov;
+    }
   }
 }
 
@@ -223,20 +260,25 @@ __global__ __launch_bounds__(256) void gate_bwd_reduce_kernel(const float* __res
 }
 
 // dmap[n,ch,p] = sum_taps dgpre[n, p - (tap-3)] * w7[ch][tap];  dW7[ch][tap] += sum_{n,p} map[n,ch,p+tap-3]*dgpre[n,p]
-// one workgroup per (row band, sample); the band's dgpre rows (+-3) and map rows (+-3) are staged in LDS
+// One workgroup per (row band, sample); the band's dgpre rows (+-3) and map rows (+-3) are staged zero padded in LDS.
+// Both parts are register blocked over XB adjacent pixels (a 7-tap row needs XB+6 window reads for 7*XB FMAs):
+//   dmap: thread <-> (channel, row, x block);   dW7: thread <-> ((channel, dy), row, x half), 7 dx accumulators,
+//   the 16 (row, half) partials of a tap are combined through LDS in a fixed order, one atomic per tap and workgroup.
 template <int BAND>
 __global__ __launch_bounds__(256) void conv7_bwd_kernel(const float* __restrict__ dgpre,
                                                          const float* __restrict__ map,
                                                          const float* __restrict__ w7, float* __restrict__ dmap,
                                                          float* __restrict__ dw7, int H, int W) {
+  constexpr int XB = 4;
   extern __shared__ float sh[];
-  const int PW = W + 6;
+  const int PW = W + 6 + XB;
+  const int plane = (BAND + 6) * PW;
   float* dsh = sh;                          // [(BAND+6)][PW]  dgpre rows y0-3 .. y0+BAND+2, zero padded
-  float* msh = sh + (BAND + 6) * PW;        // [2][(BAND+6)][PW] map rows, zero padded
+  float* msh = sh + plane;                  // [2][(BAND+6)][PW] map rows, zero padded
+  float* part = sh + 3 * plane;             // [2*BAND][98]
   __shared__ float wsh[98];
   const int n = blockIdx.y, y0 = blockIdx.x * BAND, HW = H * W, tid = threadIdx.x;
   if (tid < 98) wsh[tid] = w7[tid];
-  const int plane = (BAND + 6) * PW;
   for (int i = tid; i < 3 * plane; i += 256) {
     const int which = i / plane, r = (i % plane) / PW, cpos = (i % plane) % PW;
     const int yy = y0 - 3 + r, xx = cpos - 3;
@@ -248,28 +290,67 @@ __global__ __launch_bounds__(256) void conv7_bwd_kernel(const float* __restrict_
     sh[i] = v;
   }
   __syncthreads();
-  // dmap for the band's pixels (flipped kernel)
-  for (int i = tid; i < 2 * BAND * W; i += 256) {
-    const int ch = i / (BAND * W), r = (i % (BAND * W)) / W, x = i % W;
-    if (y0 + r >= H) continue;
-    float a = 0.f;
-    for (int dy = 0; dy < 7; ++dy)
+  // ---- dmap (flipped kernel) ----
+  const int rows = min(BAND, H - y0);
+  const int xblocks = (W + XB - 1) / XB;
+  for (int i = tid; i < 2 * rows * xblocks; i += 256) {
+    const int ch = i / (rows * xblocks), r = (i / xblocks) % rows, x0 = (i % xblocks) * XB;
+    float acc[XB];
 #pragma unroll
-      for (int dx = 0; dx < 7; ++dx) a += wsh[ch * 49 + dy * 7 + dx] * dsh[(r + 6 - dy) * PW + (x + 6 - dx)];
-    dmap[((long long)n * 2 + ch) * HW + (y0 + r) * W + x] = a;
+    for (int j = 0; j < XB; ++j) acc[j] = 0.f;
+    for (int dy = 0; dy < 7; ++dy) {
+      const float* dr = dsh + (r + 6 - dy) * PW + x0;
+      float win[XB + 6];
+#pragma unroll
+      for (int q = 0; q < XB + 6; ++q) win[q] = dr[q];
+#pragma unroll
+      for (int dx = 0; dx < 7; ++dx) {
+        const float wv = wsh[ch * 49 + dy * 7 + dx];
+#pragma unroll
+        for (int j = 0; j < XB; ++j) acc[j] += wv * win[j + 6 - dx];
+      }
+    }
+    float* dst = dmap + ((long long)n * 2 + ch) * HW + (y0 + r) * W + x0;
+#pragma unroll
+    for (int j = 0; j < XB; ++j)
+      if (x0 + j < W) dst[j] = acc[j];
   }
-  // weight gradient: thread t < 98 owns one tap and walks the band's pixels
+  // ---- weight gradient ----
+  if (tid < 14 * BAND * 2) {
+    const int chdy = tid % 14, rs = tid / 14;          // rs = row*2 + half
+    const int ch = chdy / 7, dy = chdy % 7, r = rs >> 1, hs = rs & 1;
+    const int seg = ((W + 2 * XB - 1) / (2 * XB)) * XB; // x-half length, a multiple of XB
+    const float* mr = msh + ch * plane + (r + dy) * PW;
+    const float* dr = dsh + (r + 3) * PW + 3;
+    float acc[7];
+#pragma unroll
+    for (int dx = 0; dx < 7; ++dx) acc[dx] = 0.f;
+    for (int x0 = hs * seg; x0 < min(W, (hs + 1) * seg); x0 += XB) {
+      float win[XB + 6], dv[XB];
+#pragma unroll
+      for (int q = 0; q < XB + 6; ++q) win[q] = mr[x0 + q];
+#pragma unroll
+      for (int j = 0; j < XB; ++j) dv[j] = dr[x0 + j];   // zero beyond the image (padded tile)
+#pragma unroll
+      for (int dx = 0; dx < 7; ++dx)
+#pragma unroll
+        for (int j = 0; j < XB; ++j) acc[dx] += win[j + dx] * dv[j];
+    }
+#pragma unroll
+    for (int dx = 0; dx < 7; ++dx) part[rs * 98 + ch * 49 + dy * 7 + dx] = acc[dx];
+  }
+  __syncthreads();
   if (tid < 98) {
-    const int ch = tid / 49, dy = (tid % 49) / 7, dx = tid % 7;
-    const float* mp = msh + ch * plane;
-    float a = 0.f;
-    for (int r = 0; r < BAND; ++r)
-      for (int x = 0; x < W; ++x) a += mp[(r + dy) * PW + (x + dx)] * dsh[(r + 3) * PW + (x + 3)];
-    unsafeAtomicAdd(dw7 + tid, a);
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2 * BAND; ++k) t += part[k * 98 + tid];
+    unsafeAtomicAdd(dw7 + tid, t);
   }
 }
 
-// ds[n,c] = sum_p dU * a2, with dU = dout*gate + dmapA/C + dmapM*[U==max]/cnt.  One wave per (n,c).
+// ds[n,c] = sum_p dU * a2, with dU = dout*gate + dmapA/C + dmapM*[U==max]/cnt.  One wave per (n,c), VEC pixels per lane
+// and load.
+template <int VEC>
 __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const float* __restrict__ dout,
                                                              const float* __restrict__ a2,
                                                              const float* __restrict__ s,
@@ -278,26 +359,32 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const float* __restr
                                                              const float* __restrict__ map,
                                                              const float* __restrict__ cnt, float* __restrict__ ds,
                                                              int NC, int C, int HW) {
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
   const int lane = threadIdx.x & 63;
   const int nc = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (nc >= NC) return;
   const int n = nc / C;
   const float sc = s[nc];
   const float inv_c = 1.f / (float)C;
-  const float* gp = gate + (long long)n * HW;
-  const float* da = dmap + (long long)n * 2 * HW;
-  const float* dm = da + HW;
-  const float* mx = map + ((long long)n * 2 + 1) * HW;
-  const float* ct = cnt + (long long)n * HW;
-  const float* dop = dout + (long long)nc * HW;
-  const float* ap = a2 + (long long)nc * HW;
+  const vec_t* gp = reinterpret_cast<const vec_t*>(gate + (long long)n * HW);
+  const vec_t* da = reinterpret_cast<const vec_t*>(dmap + (long long)n * 2 * HW);
+  const vec_t* dm = reinterpret_cast<const vec_t*>(dmap + ((long long)n * 2 + 1) * HW);
+  const vec_t* mx = reinterpret_cast<const vec_t*>(map + ((long long)n * 2 + 1) * HW);
+  const vec_t* ct = reinterpret_cast<const vec_t*>(cnt + (long long)n * HW);
+  const vec_t* dop = reinterpret_cast<const vec_t*>(dout + (long long)nc * HW);
+  const vec_t* ap = reinterpret_cast<const vec_t*>(a2 + (long long)nc * HW);
   float acc = 0.f;
-  for (int p = lane; p < HW; p += 64) {
-    const float a = ap[p];
-    const float u = a * sc;
-    float dU = dop[p] * gp[p] + da[p] * inv_c;
-    if (u == mx[p]) dU += dm[p] / ct[p];
-    acc += dU * a;
+  const int nv = HW / VEC;
+  for (int p = lane; p < nv; p += 64) {
+    const vec_t a = ap[p], d = dop[p], g = gp[p], va = da[p], vm = dm[p], m = mx[p], k = ct[p];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      const float av = a[q], dv = d[q], gv = g[q], vav = va[q], vmv = vm[q], mv = m[q], kv = k[q];
+      const float u = av * sc;
+      float dU = dv * gv + vav * inv_c;
+      if (u == mv) dU += vmv / kv;
+      acc += dU * av;
+    }
   }
   acc = wave_sum(acc);
   if (lane == 0) ds[nc] = acc;
@@ -337,14 +424,23 @@ int cm_spatial_stats(const float* a2, const float* s, float* map, int n, int c, 
 int cm_spatial_apply(const float* a2, const float* s, const float* map, const float* w7, float* gate, float* out,
                      int n, int c, int h, int w, cm_stream stream) {
   if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return -22;
-  const int hw = h * w;
-  const int bs = hw >= 256 ? 256 : 128;
-  const int pb = cdiv(hw, bs);
+  const int hw = h * w, bands = cdiv(h, GATE_BAND);
+  const size_t lds = (size_t)(2 * (GATE_BAND + 6) * (w + 10) + GATE_BAND * w) * sizeof(float);
+  if (lds > 60 * 1024) return -22;  // W up to ~400
   int splits = 1;
-  while ((long long)pb * n * splits < 1024 && splits * 8 <= c) splits *= 2;  // enough workgroups for 256 CUs
+  while ((long long)bands * n * splits < 1024 && splits * 8 <= c) splits *= 2;  // enough workgroups for 256 CUs
   const int cps = cdiv(c, splits);
-  spatial_apply_kernel<<<dim3(pb, n, cdiv(c, cps)), bs, 0, (hipStream_t)stream>>>(a2, s, map, w7, gate, out, c, h, w,
-                                                                                  cps);
+  const dim3 grid(bands, n, cdiv(c, cps));
+  // every band starts at a multiple of BAND*W floats inside a plane of HW floats; the last band may be shorter
+  const int last = (h - (bands - 1) * GATE_BAND) * w;
+  const bool al = (((uintptr_t)a2 | (uintptr_t)out) & 15) == 0;
+  const int band_px = GATE_BAND * w;
+  if (al && hw % 4 == 0 && band_px % 4 == 0 && last % 4 == 0)
+    spatial_apply_kernel<4><<<grid, 256, lds, (hipStream_t)stream>>>(a2, s, map, w7, gate, out, c, h, w, cps);
+  else if (al && hw % 2 == 0 && band_px % 2 == 0 && last % 2 == 0)
+    spatial_apply_kernel<2><<<grid, 256, lds, (hipStream_t)stream>>>(a2, s, map, w7, gate, out, c, h, w, cps);
+  else
+    spatial_apply_kernel<1><<<grid, 256, lds, (hipStream_t)stream>>>(a2, s, map, w7, gate, out, c, h, w, cps);
   CM_CHECK_LAUNCH();
   return 0;
 }
@@ -362,8 +458,8 @@ int cm_conv7_bwd(const float* dgpre, const float* map, const float* w7, float* d
                  cm_stream stream) {
   if (n <= 0 || h <= 0 || w <= 0) return -22;
   constexpr int BAND = 8;
-  const size_t lds = (size_t)3 * (BAND + 6) * (w + 6) * sizeof(float);
-  if (lds > 60 * 1024) return -22;  // W up to ~360
+  const size_t lds = ((size_t)3 * (BAND + 6) * (w + 10) + 2 * BAND * 98) * sizeof(float);
+  if (lds > 60 * 1024) return -22;  // W up to ~320
   conv7_bwd_kernel<BAND><<<dim3(cdiv(h, BAND), n), 256, lds, (hipStream_t)stream>>>(dgpre, map, w7, dmap, dw7, h, w);
   CM_CHECK_LAUNCH();
   return 0;
@@ -372,8 +468,15 @@ int cm_conv7_bwd(const float* dgpre, const float* map, const float* w7, float* d
 int cm_se_bwd_reduce(const float* dout, const float* a2, const float* s, const float* gate, const float* dmap,
                      const float* map, const float* cnt, float* ds, int n, int c, int hw, cm_stream stream) {
   if (n <= 0 || c <= 0 || hw <= 0) return -22;
-  se_bwd_reduce_kernel<<<cdiv((long long)n * c, 4), 256, 0, (hipStream_t)stream>>>(dout, a2, s, gate, dmap, map, cnt,
-                                                                                   ds, n * c, c, hw);
+  const unsigned grid = (unsigned)cdiv((long long)n * c, 4);
+  const bool al = (((uintptr_t)dout | (uintptr_t)a2 | (uintptr_t)gate | (uintptr_t)dmap | (uintptr_t)map |
+                    (uintptr_t)cnt) & 15) == 0;
+  if (al && hw % 4 == 0)
+    se_bwd_reduce_kernel<4><<<grid, 256, 0, (hipStream_t)stream>>>(dout, a2, s, gate, dmap, map, cnt, ds, n * c, c, hw);
+  else if (al && hw % 2 == 0)
+    se_bwd_reduce_kernel<2><<<grid, 256, 0, (hipStream_t)stream>>>(dout, a2, s, gate, dmap, map, cnt, ds, n * c, c, hw);
+  else
+    se_bwd_reduce_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(dout, a2, s, gate, dmap, map, cnt, ds, n * c, c, hw);
   CM_CHECK_LAUNCH();
   return 0;
 }
