@@ -70,6 +70,14 @@ int cm_wgrad3x3_pick_config(int n, int h, int w, int cout);
 int cm_wgrad3x3(const float* x0, long long sx0, int c0, const float* x1, long long sx1, int c1, const float* dy,
                 long long sdy, float* g, int ctot, int c_off, int n, int h, int w, int cout, int config,
                 cm_stream stream);
+/* bf16x6 form of cm_wgrad3x3 (same arguments, same staging format, fp32-equivalent accuracy; see
+ * csrc/wgrad3x3_split.hip): three bf16 pieces per fp32 operand, six v_mfma_f32_32x32x16_bf16 products, 8 samples per
+ * 16-byte LDS record so that the nine tap shifts stay aligned.  c0 must be a multiple of 32 when c1 > 0.
+ * config in [0, cm_wgrad3x3_split_num_configs()), bits 8.. = grid size in quarter rounds (0 = one round). */
+int cm_wgrad3x3_split_num_configs(void);
+int cm_wgrad3x3_split(const float* x0, long long sx0, int c0, const float* x1, long long sx1, int c1, const float* dy,
+                      long long sdy, float* g, int ctot, int c_off, int n, int h, int w, int cout, int config,
+                      cm_stream stream);
 int cm_wgrad3x3_unpack(const float* g, float* dw, int cout, int ctot, float scale, cm_stream stream);
 /* batched form: records of 8 int64 {g ptr, dw ptr, cout, ctot, 0, 0, 0, first block}, as cm_pack_conv3x3_batch */
 int cm_wgrad3x3_unpack_batch(const void* descs_dev, int ndesc, int total_blocks, float scale, cm_stream stream);
@@ -95,13 +103,20 @@ int cm_gn_silu_bwd_gated(const float* x, const float* gamma, const float* beta, 
 int cm_se_excite_fwd(const float* pooled, const float* w1, const float* w2, float* z, float* s, int n, int c, int cr,
                      cm_stream stream);
 int cm_spatial_stats(const float* a2, const float* s, float* map, int n, int c, int hw, cm_stream stream);
+/* cm_se_excite_fwd + cm_spatial_stats in one launch (same results bit for bit): z [n,cr], s [n,c], map [n,2,hw]. */
+int cm_se_spatial_stats(const float* pooled, const float* w1, const float* w2, const float* a2, float* z, float* s,
+                        float* map, int n, int c, int cr, int hw, cm_stream stream);
 int cm_spatial_apply(const float* a2, const float* s, const float* map, const float* w7, float* gate, float* out,
                      int n, int c, int h, int w, cm_stream stream);
 /* backward chain: gate_bwd_reduce -> conv7_bwd -> se_bwd_reduce -> se_excite_bwd -> cm_gn_silu_bwd_gated */
 int cm_gate_bwd_reduce(const float* dout, const float* a2, const float* s, const float* gate, const float* map,
                        float* dgpre, float* cnt, int n, int c, int hw, cm_stream stream);
+/* `scratch`: cm_conv7_bwd_scratch_elems(n, h) floats of workspace (per-workgroup partial dW7 sums, no initialisation
+ * needed): thousands of workgroups adding into the same 98 addresses serialise in the L2, so the partials are stored
+ * and folded by a second tiny kernel inside the same call. */
+long long cm_conv7_bwd_scratch_elems(int n, int h);
 int cm_conv7_bwd(const float* dgpre, const float* map, const float* w7, float* dmap, float* dw7 /* accumulated */,
-                 int n, int h, int w, cm_stream stream);
+                 float* scratch, int n, int h, int w, cm_stream stream);
 int cm_se_bwd_reduce(const float* dout, const float* a2, const float* s, const float* gate, const float* dmap,
                      const float* map, const float* cnt, float* ds, int n, int c, int hw, cm_stream stream);
 /* dsig [n,c], dz [n,cr], dpool [n,c] are outputs; dw1 [cr,c], dw2 [c,cr] are ACCUMULATED. */

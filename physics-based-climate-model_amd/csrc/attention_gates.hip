@@ -141,20 +141,77 @@ __global__ __launch_bounds__(256) void spatial_stats_kernel(const float* __restr
   }
 }
 
+// SE excite + spatial statistics in one launch: every workgroup recomputes its sample's s = sigmoid(W2 relu(W1 p)) into
+// LDS (2*C*Cr MACs, nothing next to its 64 x C pixel reads; bit-identical across workgroups: same order), the first
+// pixel block of each sample also stores z and s for the backward pass.
+__global__ __launch_bounds__(256) void se_spatial_stats_kernel(const float* __restrict__ pooled,
+                                                                const float* __restrict__ w1,
+                                                                const float* __restrict__ w2,
+                                                                const float* __restrict__ a2, float* __restrict__ z,
+                                                                float* __restrict__ s, float* __restrict__ map, int C,
+                                                                int Cr, int HW) {
+  extern __shared__ float sh[];  // [C] pooled, then s; [Cr] hidden
+  __shared__ float ssum[4][64], smax[4][64];
+  float* p = sh;
+  float* hsh = sh + C;
+  const int n = blockIdx.y, tid = threadIdx.x;
+  const int lane = tid & 63, slice = tid >> 6;
+  for (int c = tid; c < C; c += 256) p[c] = pooled[(long long)n * C + c];
+  __syncthreads();
+  for (int r = slice; r < Cr; r += 4) {
+    float a = 0.f;
+    for (int c = lane; c < C; c += 64) a += w1[(long long)r * C + c] * p[c];
+    a = wave_sum(a);
+    if (lane == 0) {
+      if (blockIdx.x == 0) z[(long long)n * Cr + r] = a;
+      hsh[r] = fmaxf(a, 0.f);
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float a = 0.f;
+    for (int r = 0; r < Cr; ++r) a += w2[(long long)c * Cr + r] * hsh[r];
+    const float sv = sigmoid_acc(a);
+    p[c] = sv;                                       // pooled[c] is dead: every thread only rewrites its own c
+    if (blockIdx.x == 0) s[(long long)n * C + c] = sv;
+  }
+  __syncthreads();
+  const int px = blockIdx.x * 64 + lane;
+  const bool live = px < HW;
+  const float* ap = a2 + (long long)n * C * HW + (live ? px : 0);
+  const int cper = (C + 3) / 4, c0 = slice * cper, c1 = min(C, c0 + cper);
+  float sum = 0.f, mx = -INFINITY;
+#pragma unroll 8
+  for (int c = c0; c < c1; ++c) {
+    const float u = ap[(long long)c * HW] * p[c];
+    sum += u;
+    mx = fmaxf(mx, u);
+  }
+  ssum[slice][lane] = sum;
+  smax[slice][lane] = mx;
+  __syncthreads();
+  if (slice == 0 && live) {
+    const float t = ((ssum[0][lane] + ssum[1][lane]) + ssum[2][lane]) + ssum[3][lane];
+    const float m = fmaxf(fmaxf(smax[0][lane], smax[1][lane]), fmaxf(smax[2][lane], smax[3][lane]));
+    map[((long long)n * 2) * HW + px] = t / (float)C;
+    map[((long long)n * 2 + 1) * HW + px] = m;
+  }
+}
+
 // gate = sigmoid(conv7x7(map)); out = a2 * s * gate.
 // Workgroup = (row band, sample, channel split): the band's map rows (+-3, zero padded) are staged in LDS, the gate of
 // the band's pixels is computed once into LDS (XB adjacent pixels per thread share their 7x(XB+6) window reads), then
 // the band -- a contiguous run of BAND*W floats per channel -- is streamed with VEC-wide accesses.
 constexpr int GATE_BAND = 8;
-template <int VEC>
+template <int VEC, int XB>
 __global__ __launch_bounds__(256) void spatial_apply_kernel(const float* __restrict__ a2, const float* __restrict__ s,
                                                              const float* __restrict__ map,
                                                              const float* __restrict__ w7, float* __restrict__ gate,
                                                              float* __restrict__ out, int C, int H, int W,
                                                              int c_per_split) {
-  constexpr int BAND = GATE_BAND, XB = 4;
+  constexpr int BAND = GATE_BAND;
   extern __shared__ float sh[];
-  const int PW = W + 6 + XB;                   // row pitch of the padded map tile (room for the XB overshoot)
+  const int PW = W + 6 + 4;                    // row pitch of the padded map tile (room for the XB <= 4 overshoot)
   float* msh = sh;                             // [2][BAND+6][PW]
   float* gsh = sh + 2 * (BAND + 6) * PW;       // [BAND*W] gate of the band
   __shared__ float wsh[98];
@@ -204,8 +261,10 @@ __global__ __launch_bounds__(256) void spatial_apply_kernel(const float* __restr
   const int nv = npx / VEC;                    // host guarantees npx % VEC == 0 and aligned bases
   const float* sp = s + (long long)n * C;
   typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  const unsigned magic = 0xFFFFFFFFu / (unsigned)max(nv, 1) + 1u;   // i / nv == umulhi(i, magic) for i*nv < 2^32
   for (int i = tid; i < nc * nv; i += 256) {
-    const int c = c0 + i / nv, v = i % nv;
+    const int q = nv == 1 ? i : (int)__umulhi((unsigned)i, magic);   // (magic overflows to 0 for nv == 1)
+    const int c = c0 + q, v = i - q * nv;
     const long long off = ((long long)n * C + c) * HW + y0 * W + v * VEC;
     const float sc = sp[c];
     if constexpr (VEC == 1) {
@@ -268,7 +327,7 @@ template <int BAND>
 __global__ __launch_bounds__(256) void conv7_bwd_kernel(const float* __restrict__ dgpre,
                                                          const float* __restrict__ map,
                                                          const float* __restrict__ w7, float* __restrict__ dmap,
-                                                         float* __restrict__ dw7, int H, int W) {
+                                                         float* __restrict__ partials, int H, int W) {
   constexpr int XB = 4;
   extern __shared__ float sh[];
   const int PW = W + 6 + XB;
@@ -340,12 +399,34 @@ __global__ __launch_bounds__(256) void conv7_bwd_kernel(const float* __restrict_
     for (int dx = 0; dx < 7; ++dx) part[rs * 98 + ch * 49 + dy * 7 + dx] = acc[dx];
   }
   __syncthreads();
+  // Thousands of workgroups adding into the same 98 addresses serialise in the L2 (measured: +15 us at 1152
+  // workgroups); every workgroup stores its 98 partial sums instead and conv7_fold_kernel adds them up.
   if (tid < 98) {
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 2 * BAND; ++k) t += part[k * 98 + tid];
-    unsafeAtomicAdd(dw7 + tid, t);
+    partials[(long long)(blockIdx.y * gridDim.x + blockIdx.x) * 98 + tid] = t;
   }
+}
+
+// dw7[tap] += sum_rows partials[row][tap]; workgroup b takes rows [b*rpb, (b+1)*rpb), two row-interleaved halves
+__global__ __launch_bounds__(256) void conv7_fold_kernel(const float* __restrict__ partials, int nrows, int rpb,
+                                                          float* __restrict__ dw7) {
+  __shared__ float sh[128];
+  const int tap = threadIdx.x & 127, hs = threadIdx.x >> 7;
+  const int r0 = blockIdx.x * rpb, r1 = min(nrows, r0 + rpb);
+  float a0 = 0.f, a1 = 0.f;
+  if (tap < 98) {
+    int r = r0 + hs;
+    for (; r + 2 < r1; r += 4) {
+      a0 += partials[(long long)r * 98 + tap];
+      a1 += partials[(long long)(r + 2) * 98 + tap];
+    }
+    if (r < r1) a0 += partials[(long long)r * 98 + tap];
+  }
+  if (hs == 1) sh[tap] = a0 + a1;
+  __syncthreads();
+  if (hs == 0 && tap < 98) unsafeAtomicAdd(dw7 + tap, (a0 + a1) + sh[tap]);
 }
 
 // ds[n,c] = sum_p dU * a2, with dU = dout*gate + dmapA/C + dmapM*[U==max]/cnt.  One wave per (n,c), VEC pixels per lane
@@ -421,6 +502,15 @@ int cm_spatial_stats(const float* a2, const float* s, float* map, int n, int c, 
   return 0;
 }
 
+int cm_se_spatial_stats(const float* pooled, const float* w1, const float* w2, const float* a2, float* z, float* s,
+                        float* map, int n, int c, int cr, int hw, cm_stream stream) {
+  if (n <= 0 || c <= 0 || cr <= 0 || hw <= 0) return -22;
+  se_spatial_stats_kernel<<<dim3(cdiv(hw, 64), n), 256, (c + cr) * sizeof(float), (hipStream_t)stream>>>(
+      pooled, w1, w2, a2, z, s, map, c, cr, hw);
+  CM_CHECK_LAUNCH();
+  return 0;
+}
+
 int cm_spatial_apply(const float* a2, const float* s, const float* map, const float* w7, float* gate, float* out,
                      int n, int c, int h, int w, cm_stream stream) {
   if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return -22;
@@ -435,12 +525,16 @@ int cm_spatial_apply(const float* a2, const float* s, const float* map, const fl
   const int last = (h - (bands - 1) * GATE_BAND) * w;
   const bool al = (((uintptr_t)a2 | (uintptr_t)out) & 15) == 0;
   const int band_px = GATE_BAND * w;
-  if (al && hw % 4 == 0 && band_px % 4 == 0 && last % 4 == 0)
-    spatial_apply_kernel<4><<<grid, 256, lds, (hipStream_t)stream>>>(a2, s, map, w7, gate, out, c, h, w, cps);
-  else if (al && hw % 2 == 0 && band_px % 2 == 0 && last % 2 == 0)
-    spatial_apply_kernel<2><<<grid, 256, lds, (hipStream_t)stream>>>(a2, s, map, w7, gate, out, c, h, w, cps);
-  else
-    spatial_apply_kernel<1><<<grid, 256, lds, (hipStream_t)stream>>>(a2, s, map, w7, gate, out, c, h, w, cps);
+  const int vec = (al && hw % 4 == 0 && band_px % 4 == 0 && last % 4 == 0)   ? 4
+                  : (al && hw % 2 == 0 && band_px % 2 == 0 && last % 2 == 0) ? 2
+                                                                             : 1;
+  const int xb = w >= 64 ? 4 : (w >= 32 ? 2 : 1);   // gate phase: ~150 busy threads per band at every level
+#define CM_APPLY(V, X)                                                                                          \
+  if (vec == V && xb == X)                                                                                      \
+    spatial_apply_kernel<V, X><<<grid, 256, lds, (hipStream_t)stream>>>(a2, s, map, w7, gate, out, c, h, w, cps);
+  CM_APPLY(4, 4) CM_APPLY(4, 2) CM_APPLY(4, 1) CM_APPLY(2, 4) CM_APPLY(2, 2) CM_APPLY(2, 1) CM_APPLY(1, 4)
+  CM_APPLY(1, 2) CM_APPLY(1, 1)
+#undef CM_APPLY
   CM_CHECK_LAUNCH();
   return 0;
 }
@@ -454,13 +548,21 @@ int cm_gate_bwd_reduce(const float* dout, const float* a2, const float* s, const
   return 0;
 }
 
-int cm_conv7_bwd(const float* dgpre, const float* map, const float* w7, float* dmap, float* dw7, int n, int h, int w,
-                 cm_stream stream) {
-  if (n <= 0 || h <= 0 || w <= 0) return -22;
+long long cm_conv7_bwd_scratch_elems(int n, int h) {
+  return (n <= 0 || h <= 0) ? -22 : (long long)n * cdiv(h, 8) * 98;
+}
+
+int cm_conv7_bwd(const float* dgpre, const float* map, const float* w7, float* dmap, float* dw7, float* scratch, int n,
+                 int h, int w, cm_stream stream) {
+  if (n <= 0 || h <= 0 || w <= 0 || !scratch) return -22;
   constexpr int BAND = 8;
   const size_t lds = ((size_t)3 * (BAND + 6) * (w + 10) + 2 * BAND * 98) * sizeof(float);
   if (lds > 60 * 1024) return -22;  // W up to ~320
-  conv7_bwd_kernel<BAND><<<dim3(cdiv(h, BAND), n), 256, lds, (hipStream_t)stream>>>(dgpre, map, w7, dmap, dw7, h, w);
+  const int bands = cdiv(h, BAND), nrows = bands * n;
+  conv7_bwd_kernel<BAND><<<dim3(bands, n), 256, lds, (hipStream_t)stream>>>(dgpre, map, w7, dmap, scratch, h, w);
+  CM_CHECK_LAUNCH();
+  const int fb = max(1, min(8, nrows / 32)), rpb = cdiv(nrows, fb);
+  conv7_fold_kernel<<<cdiv(nrows, rpb), 256, 0, (hipStream_t)stream>>>(scratch, nrows, rpb, dw7);
   CM_CHECK_LAUNCH();
   return 0;
 }

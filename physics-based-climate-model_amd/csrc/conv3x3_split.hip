@@ -17,30 +17,12 @@
 //     shared by the workgroup's waves (reading the fragments straight from L2 in every wave cost ~60 % of a CU's L2
 //     bandwidth and 24-48 VGPRs of ping-pong registers).
 #include "common.h"
+#include "split_bf16.h"
 #include "../../include/climate_hip.h"
 
 namespace {
 
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
 constexpr int SKC = 16;   // input channels per LDS stage = one 16-deep MFMA k-step per tap
-
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-
-// Split two floats into three packed bf16 pairs (element 0 in the low half).  The vector convert lowers to
-// v_cvt_pk_bf16_f32 (round-to-nearest-even); each residual v - float(piece) is exact in fp32.
-__device__ __forceinline__ void split3_pair(float v0, float v1, unsigned& ph, unsigned& pm, unsigned& pl) {
-  f32x2_t v = {v0, v1};
-  ph = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
-  f32x2_t hf = {__uint_as_float(ph << 16), __uint_as_float(ph & 0xffff0000u)};
-  const f32x2_t r1 = v - hf;
-  pm = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2_t));
-  f32x2_t mf = {__uint_as_float(pm << 16), __uint_as_float(pm & 0xffff0000u)};
-  const f32x2_t r2 = r1 - mf;
-  pl = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2_t));
-}
 
 struct SplitArgs {
   const float* in0;

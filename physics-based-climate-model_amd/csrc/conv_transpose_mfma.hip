@@ -9,8 +9,8 @@
 //   weight  : dW[c][(o,k)] =       sum_p  X[c, p] * dY[(o,k), p]             rows c, cols (o,k), K = N*H*W
 //
 // These GEMMs are tiny (0.45 GFLOP per decoder level at the benchmark shape) and their cost is launch width and load
-// latency, not arithmetic.  forward/data: a workgroup owns a 32-row x 64-pixel tile and its four waves SPLIT THE
-// REDUCTION four ways (operands straight from global memory in MFMA fragment order, all loads of a wave in flight at
+// latency, not arithmetic.  forward/data: a workgroup owns a 32-row x 32-pixel tile and its eight waves SPLIT THE
+// REDUCTION eight ways (operands straight from global memory in MFMA fragment order, all loads of a wave in flight at
 // once), then combine through LDS.  weight: 64x64 tiles, pixel chunks transposed through LDS, reduction split over
 // blockIdx.z with float atomics on 128-byte segments.
 #include "common.h"
@@ -18,14 +18,20 @@
 
 namespace {
 
-constexpr int UNR = 16;   // k-steps (of 2) whose fragment loads are issued before their MFMAs
+constexpr int UNR = 16;   // k-steps (of 2) per round: all fragment loads of a round are issued before its MFMAs
+constexpr int NWV = 8;    // waves per workgroup = reduction split
 
 template <bool BWD>
-__global__ __launch_bounds__(256) void convT_mfma_kernel(const float* __restrict__ src, long long ssrc,
-                                                          const float* __restrict__ w, const float* __restrict__ bias,
-                                                          float* __restrict__ dst, long long sdst, int N, int Ci, int Co,
-                                                          int H, int W) {
-  __shared__ float red[4][2][16][64];
+__global__ __launch_bounds__(NWV * 64) void convT_mfma_kernel(const float* __restrict__ src, long long ssrc,
+                                                               const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ dst,
+                                                               long long sdst, int N, int Ci, int Co, int H, int W) {
+  // backward: the weight rows are contiguous along the REDUCTION index, so A fragments (lanes = rows) straight from
+  // global memory would touch 32 cache lines per load; each wave stages its [32 rows][2*UNR] slab through LDS with
+  // coalesced loads instead.  The slabs are dead when the partial tiles are combined, so `red` aliases them.
+  constexpr int SLAB = 32 * (2 * UNR + 1);
+  constexpr int RED = NWV * 16 * 64;
+  __shared__ float smem[(BWD && NWV * SLAB > RED) ? NWV * SLAB : RED];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, half = lane >> 5;
   const int HW = H * W, Wo = 2 * W, M4 = 4 * Co;
@@ -33,103 +39,98 @@ __global__ __launch_bounds__(256) void convT_mfma_kernel(const float* __restrict
   const int K = BWD ? M4 : Ci;             // GEMM K
   const long long NP = (long long)N * HW;
   const int mt = blockIdx.y;
-  const long long pt0 = (long long)blockIdx.x * 2;     // first of this workgroup's two 32-pixel tiles
-  const int kw = ((K + 7) / 8) * 2;                    // this wave's share of the reduction (even)
+  const int kw = ((K + 2 * NWV - 1) / (2 * NWV)) * 2;  // this wave's share of the reduction (even)
   const int kbeg = wave * kw, kend = min(K, kbeg + kw);
 
-  // A fragment addressing: forward A[i][kk] = w[kk*M4 + i] (i contiguous); backward A[i][kk] = w[i*M4 + kk]
+  // forward A[i][kk] = w[kk*M4 + i] (i contiguous)
   const int ai = mt * 32 + l31;
   const bool aok = ai < rows;
-  const long long abase = BWD ? (long long)(aok ? ai : 0) * M4 : (aok ? ai : 0);
-  const long long astep = BWD ? 1 : M4;
 
-  long long bbase[2];
-  bool bok[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const long long gp = (pt0 + t) * 32 + l31;
-    bok[t] = gp < NP;
-    const long long g2 = bok[t] ? gp : 0;
-    const int n = (int)(g2 / HW), p = (int)(g2 % HW);
-    if (!BWD) {
-      bbase[t] = (long long)n * ssrc + p;                                  // X[n, c, p]: + c*HW
-    } else {
-      const int yy = p / W, xx = p % W;
-      bbase[t] = (long long)n * ssrc + (long long)(2 * yy) * Wo + 2 * xx;  // dY[n, o, 2y+ky, 2x+kx]: + o*4HW + ky*Wo + kx
-    }
-  }
+  const long long gp = (long long)blockIdx.x * 32 + l31;
+  const bool bok = gp < NP;
+  const int pn = (int)((bok ? gp : 0) / HW), pp = (int)((bok ? gp : 0) % HW);
+  const int py = pp / W, px = pp % W;
+  // X[n, c, p]: + c*HW          dY[n, o, 2y+ky, 2x+kx]: + o*4HW + ky*Wo + kx
+  const long long bbase = BWD ? (long long)pn * ssrc + (long long)(2 * py) * Wo + 2 * px : (long long)pn * ssrc + pp;
 
-  f32x16 acc[2];
+  f32x16 acc;
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
+  float* slab = smem + wave * SLAB;
   for (int k0 = kbeg; k0 < kend; k0 += 2 * UNR) {
-    float av[UNR], bv[2][UNR];
+    if (BWD) {
+      __builtin_amdgcn_wave_barrier();
+      // 2*UNR = 32 reduction indices x 32 rows: lane -> (row parity, k), 16 loads of two rows each
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int r = 2 * q + half, row = mt * 32 + r, kk = k0 + l31;
+        const bool ok = row < rows && kk < kend;
+        const float v = w[ok ? (long long)row * M4 + kk : 0];
+        slab[r * (2 * UNR + 1) + l31] = ok ? v : 0.f;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    float av[UNR], bv[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int kk = k0 + 2 * u + half;
       const bool kok = kk < kend;
       const int kc = kok ? kk : 0;
-      const float a = w[abase + (long long)kc * astep];
-      av[u] = (kok && aok) ? a : 0.f;
+      if (BWD) {
+        av[u] = slab[l31 * (2 * UNR + 1) + 2 * u + half];
+      } else {
+        const float a = w[(long long)kc * M4 + (aok ? ai : 0)];
+        av[u] = (kok && aok) ? a : 0.f;
+      }
       long long boff;
       if (!BWD) boff = (long long)kc * HW;
       else boff = (long long)(kc >> 2) * 4 * HW + ((kc >> 1) & 1) * Wo + (kc & 1);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const float b = src[bbase[t] + boff];
-        bv[t][u] = (kok && bok[t]) ? b : 0.f;
-      }
+      const float b = src[bbase + boff];
+      bv[u] = (kok && bok) ? b : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < UNR; ++u)
-#pragma unroll
-      for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[t][u], acc[t], 0, 0, 0);
+    for (int u = 0; u < UNR; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
   }
 
-  // combine the four partial tiles: wave q finishes accumulator registers 4q..4q+3 of both pixel tiles
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave][t][r][lane] = acc[t][r];
+  // combine the NWV partial tiles: wave q finishes accumulator registers 2q, 2q+1
   __syncthreads();
-  const int g4 = wave;
+  float(*red)[16][64] = reinterpret_cast<float(*)[16][64]>(smem);
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    float v[4];
+  for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+  __syncthreads();
+  float v[2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      v[q] = (red[0][t][4 * g4 + q][lane] + red[1][t][4 * g4 + q][lane]) +
-             (red[2][t][4 * g4 + q][lane] + red[3][t][4 * g4 + q][lane]);
-    if (!bok[t]) continue;
-    const long long gp = (pt0 + t) * 32 + l31;
-    const int n = (int)(gp / HW), p = (int)(gp % HW);
-    // D[i][j]: lane holds column j = l31 (pixel), rows (r&3) + 8*(r>>2) + 4*half
-    if (!BWD) {
-      const int yy = p / W, xx = p % W;
-      const int o = mt * 8 + 2 * g4 + half;      // rows 4*o .. 4*o+3 are this output channel's four taps
-      if (o < Co) {
-        const float bb = bias ? bias[o] : 0.f;
-        float* yp = dst + (long long)n * sdst + (long long)o * 4 * HW + (long long)(2 * yy) * Wo + 2 * xx;
-        *reinterpret_cast<float2*>(yp) = make_float2(v[0] + bb, v[1] + bb);
-        *reinterpret_cast<float2*>(yp + Wo) = make_float2(v[2] + bb, v[3] + bb);
-      }
-    } else {
+  for (int q = 0; q < 2; ++q) {
+    float t = 0.f;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c = mt * 32 + q + 8 * g4 + 4 * half;
-        if (c < Ci) dst[(long long)n * sdst + (long long)c * HW + p] = v[q];
-      }
+    for (int k = 0; k < NWV; ++k) t += red[k][2 * wave + q][lane];
+    v[q] = t;
+  }
+  if (!bok) return;
+  // D[i][j]: lane holds column j = l31 (pixel), rows (r&3) + 8*(r>>2) + 4*half
+  if (!BWD) {
+    const int g4 = wave >> 1, ky = wave & 1;     // registers 4*g4 + 2*ky + {0,1}: output row 2y+ky of channel o
+    const int o = mt * 8 + 2 * g4 + half;
+    if (o < Co) {
+      const float bb = bias ? bias[o] : 0.f;
+      float* yp = dst + (long long)pn * sdst + (long long)o * 4 * HW + (long long)(2 * py + ky) * Wo + 2 * px;
+      *reinterpret_cast<float2*>(yp) = make_float2(v[0] + bb, v[1] + bb);
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int r = 2 * wave + q;
+      const int c = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (c < Ci) dst[(long long)pn * sdst + (long long)c * HW + pp] = v[q];
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------- weight gradient
 // Workgroup tile: 64 input channels x 64 (o,k) columns (= 16 output channels), waves 2x2, each a 32x32 MFMA tile.
-// Pixel chunks of 32 are loaded coalesced along the pixel index and transposed through LDS (odd pitch).
-constexpr int WPX = 32;
+// Pixel chunks of 64 are loaded coalesced along the pixel index and transposed through LDS (odd pitch).
+constexpr int WPX = 64;
 __global__ __launch_bounds__(256) void convT_wgrad_mfma_kernel(const float* __restrict__ x, long long sx,
                                                                 const float* __restrict__ dy, long long sdy,
                                                                 float* __restrict__ dw, int N, int Ci, int Co, int H,
@@ -150,10 +151,10 @@ __global__ __launch_bounds__(256) void convT_wgrad_mfma_kernel(const float* __re
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  // staging roles: X: 8 values per thread (pixel = tid%32, channels tid/32 + 8q); dY: 4 float2 per thread
-  const int spx = tid & 31, sgrp = tid >> 5;
-  float xr[8];
-  float2 dr[4];
+  // staging roles: X: 16 values per thread (pixel = tid%64, channels tid/64 + 4q); dY: 8 float2 per thread
+  const int spx = tid & 63, sgrp = tid >> 6;
+  float xr[16];
+  float2 dr[8];
   auto load = [&](long long ch) {
     const long long gp = ch * WPX + spx;
     const bool pok = gp < NP;
@@ -163,15 +164,15 @@ __global__ __launch_bounds__(256) void convT_wgrad_mfma_kernel(const float* __re
     const float* xp = x + (long long)n * sx + p;
     const float* dp = dy + (long long)n * sdy + (long long)(2 * yy) * Wo + 2 * xx;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int c = c0 + sgrp + 8 * q;
+    for (int q = 0; q < 16; ++q) {
+      const int c = c0 + sgrp + 4 * q;
       const bool ok = pok && c < Ci;
       const float v = xp[ok ? (long long)c * HW : 0];
       xr[q] = ok ? v : 0.f;
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int oo = (sgrp + 8 * q) >> 1, ky = (sgrp + 8 * q) & 1;      // 16 channels x 2 rows
+    for (int q = 0; q < 8; ++q) {
+      const int oo = (sgrp + 4 * q) >> 1, ky = (sgrp + 4 * q) & 1;      // 16 channels x 2 rows
       const bool ok = pok && o0 + oo < Co;
       const float2 v = *reinterpret_cast<const float2*>(dp + (ok ? (long long)(o0 + oo) * 4 * HW + ky * Wo : 0));
       dr[q] = ok ? v : make_float2(0.f, 0.f);
@@ -179,10 +180,10 @@ __global__ __launch_bounds__(256) void convT_wgrad_mfma_kernel(const float* __re
   };
   auto store = [&]() {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) Xs[sgrp + 8 * q][spx] = xr[q];
+    for (int q = 0; q < 16; ++q) Xs[sgrp + 4 * q][spx] = xr[q];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int oo = (sgrp + 8 * q) >> 1, ky = (sgrp + 8 * q) & 1;
+    for (int q = 0; q < 8; ++q) {
+      const int oo = (sgrp + 4 * q) >> 1, ky = (sgrp + 4 * q) & 1;
       Ds[oo * 4 + ky * 2][spx] = dr[q].x;
       Ds[oo * 4 + ky * 2 + 1][spx] = dr[q].y;
     }
@@ -219,8 +220,8 @@ int cm_convT2x2_fwd(const float* x, long long sx, const float* w, const float* b
                     int ci, int co, int h, int w_, cm_stream stream) {
   if (n <= 0 || ci <= 0 || co <= 0 || h <= 0 || w_ <= 0 || (sy & 1)) return -22;
   const long long np = (long long)n * h * w_;
-  dim3 grid((unsigned)((np + 63) / 64), (unsigned)((4 * co + 31) / 32));
-  convT_mfma_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(x, sx, w, b, y, sy, n, ci, co, h, w_);
+  dim3 grid((unsigned)((np + 31) / 32), (unsigned)((4 * co + 31) / 32));
+  convT_mfma_kernel<false><<<grid, NWV * 64, 0, (hipStream_t)stream>>>(x, sx, w, b, y, sy, n, ci, co, h, w_);
   CM_CHECK_LAUNCH();
   return 0;
 }
@@ -229,8 +230,8 @@ int cm_convT2x2_bwd_data(const float* dy, long long sdy, const float* w, float* 
                          int co, int h, int w_, cm_stream stream) {
   if (n <= 0 || ci <= 0 || co <= 0 || h <= 0 || w_ <= 0 || (sdy & 1)) return -22;
   const long long np = (long long)n * h * w_;
-  dim3 grid((unsigned)((np + 63) / 64), (unsigned)((ci + 31) / 32));
-  convT_mfma_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(dy, sdy, w, nullptr, dx, sdx, n, ci, co, h, w_);
+  dim3 grid((unsigned)((np + 31) / 32), (unsigned)((ci + 31) / 32));
+  convT_mfma_kernel<true><<<grid, NWV * 64, 0, (hipStream_t)stream>>>(dy, sdy, w, nullptr, dx, sdx, n, ci, co, h, w_);
   CM_CHECK_LAUNCH();
   return 0;
 }
@@ -240,7 +241,7 @@ int cm_convT2x2_bwd_weight(const float* x, long long sx, const float* dy, long l
   if (n <= 0 || ci <= 0 || co <= 0 || h <= 0 || w_ <= 0 || (sdy & 1)) return -22;
   const long long nchunks = ((long long)n * h * w_ + WPX - 1) / WPX;
   const int gx = cdiv(ci, 64), gy = cdiv(co, 16);
-  long long splits = cdiv(1024, gx * gy);
+  long long splits = cdiv(512, gx * gy);   // float atomics per workgroup (4096) vs serial chunks per workgroup
   if (splits > nchunks) splits = nchunks;
   if (splits < 1) splits = 1;
   const int cpb = (int)((nchunks + splits - 1) / splits);

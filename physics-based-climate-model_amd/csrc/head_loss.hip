@@ -52,45 +52,53 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred
 // A workgroup walks `ppb` pixels of one sample; per 16-channel chunk every thread keeps its dW partials in registers
 // over all its pixels and the cross-lane reduction happens once per (o, c), not once per pixel tile.
 constexpr int HB_CC = 16;
+template <int OCT>   // OCT >= OC: compile-time bound of the output-channel loops (register arrays sized by it)
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dpred, const float* __restrict__ x,
                                                         long long sx, const float* __restrict__ w,
                                                         float* __restrict__ dx, long long sdx,
                                                         float* __restrict__ dw, float* __restrict__ db, int C,
                                                         int OC, int HW, int ppb) {
-  extern __shared__ float sh[];  // [OC*C] dW partial + [OC] db partial
+  extern __shared__ float sh[];  // [OC*C] dW partial + [OC] db partial + [OC*C] weights
   const int tid = threadIdx.x, lane = tid & 63;
   const int n = blockIdx.y;
   const int p_begin = blockIdx.x * ppb, p_end = min(HW, p_begin + ppb);
+  float* wsh = sh + OC * C + OC;
   for (int i = tid; i < OC * C + OC; i += 256) sh[i] = 0.f;
+  for (int i = tid; i < OC * C; i += 256) wsh[i] = w[i];
   __syncthreads();
-  float dbp[MAXOC];
+  float dbp[OCT];
 #pragma unroll
-  for (int o = 0; o < MAXOC; ++o) dbp[o] = 0.f;
+  for (int o = 0; o < OCT; ++o) dbp[o] = 0.f;
   for (int c0 = 0; c0 < C; c0 += HB_CC) {
-    float dwp[MAXOC][HB_CC];
+    float dwp[OCT][HB_CC];
 #pragma unroll
-    for (int o = 0; o < MAXOC; ++o)
+    for (int o = 0; o < OCT; ++o)
 #pragma unroll
       for (int j = 0; j < HB_CC; ++j) dwp[o][j] = 0.f;
     for (int p = p_begin + tid; p < p_end; p += 256) {
-      float dp[MAXOC];
+      float dp[OCT];
 #pragma unroll
-      for (int o = 0; o < MAXOC; ++o) dp[o] = (o < OC) ? dpred[((long long)n * OC + o) * HW + p] : 0.f;
+      for (int o = 0; o < OCT; ++o) dp[o] = (o < OC) ? dpred[((long long)n * OC + o) * HW + p] : 0.f;
       if (c0 == 0) {
 #pragma unroll
-        for (int o = 0; o < MAXOC; ++o) dbp[o] += dp[o];
+        for (int o = 0; o < OCT; ++o) dbp[o] += dp[o];
+      }
+      float xv[HB_CC];
+#pragma unroll
+      for (int j = 0; j < HB_CC; ++j) {
+        const int c = min(c0 + j, C - 1);
+        xv[j] = x[(long long)n * sx + (long long)c * HW + p];
       }
 #pragma unroll
       for (int j = 0; j < HB_CC; ++j) {
         const int c = c0 + j;
         if (c < C) {
-          const float xv = x[(long long)n * sx + (long long)c * HW + p];
           float g = 0.f;
 #pragma unroll
-          for (int o = 0; o < MAXOC; ++o) {
+          for (int o = 0; o < OCT; ++o) {
             if (o < OC) {
-              g += w[o * C + c] * dp[o];
-              dwp[o][j] += dp[o] * xv;
+              g += wsh[o * C + c] * dp[o];
+              dwp[o][j] += dp[o] * xv[j];
             }
           }
           dx[(long long)n * sdx + (long long)c * HW + p] = g;
@@ -98,7 +106,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
       }
     }
 #pragma unroll
-    for (int o = 0; o < MAXOC; ++o) {
+    for (int o = 0; o < OCT; ++o) {
       if (o < OC) {
 #pragma unroll
         for (int j = 0; j < HB_CC; ++j) {
@@ -111,7 +119,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     }
   }
 #pragma unroll
-  for (int o = 0; o < MAXOC; ++o) {
+  for (int o = 0; o < OCT; ++o) {
     if (o < OC) {
       const float sred = wave_sum(dbp[o]);
       if (lane == 0) atomicAdd(&sh[OC * C + o], sred);
@@ -151,8 +159,14 @@ int cm_head_bwd(const float* dpred, const float* x, long long sx, const float* w
   int parts = 1;
   while (n * parts < 256 && hw / (parts * 2) >= 256) parts *= 2;   // >= 256 pixels per workgroup
   const int ppb = cdiv(hw, parts);
-  head_bwd_kernel<<<dim3(cdiv(hw, ppb), n), 256, (oc * c + oc) * sizeof(float), (hipStream_t)stream>>>(
-      dpred, x, sx, w, dx, sdx, dw, db, c, oc, hw, ppb);
+  const dim3 grid(cdiv(hw, ppb), n);
+  const size_t lds = (size_t)(2 * oc * c + oc) * sizeof(float);
+  if (oc <= 2)
+    head_bwd_kernel<2><<<grid, 256, lds, (hipStream_t)stream>>>(dpred, x, sx, w, dx, sdx, dw, db, c, oc, hw, ppb);
+  else if (oc <= 4)
+    head_bwd_kernel<4><<<grid, 256, lds, (hipStream_t)stream>>>(dpred, x, sx, w, dx, sdx, dw, db, c, oc, hw, ppb);
+  else
+    head_bwd_kernel<MAXOC><<<grid, 256, lds, (hipStream_t)stream>>>(dpred, x, sx, w, dx, sdx, dw, db, c, oc, hw, ppb);
   CM_CHECK_LAUNCH();
   return 0;
 }

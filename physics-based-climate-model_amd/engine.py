@@ -170,8 +170,8 @@ def _block_fwd(p: Params, pk, prefix: str, x0: Tensor, x1: Optional[Tensor], sav
     a1, st1, _ = ops.gn_silu_fwd(y1, p[prefix + "body.1.weight"], p[prefix + "body.1.bias"])
     y2 = pk.conv(prefix + "body.3.weight/f", a1, co)
     a2, st2, pooled = ops.gn_silu_fwd(y2, p[prefix + "body.4.weight"], p[prefix + "body.4.bias"], want_pooled=True)
-    z, s = ops.se_excite_fwd(pooled, p[prefix + "se.fc.0.weight"], p[prefix + "se.fc.2.weight"])
-    out, fmap, gate = ops.spatial_gate_fwd(a2, s, p[prefix + "spat.conv.weight"])
+    out, z, s, fmap, gate = ops.se_spatial_gate_fwd(a2, pooled, p[prefix + "se.fc.0.weight"],
+                                                    p[prefix + "se.fc.2.weight"], p[prefix + "spat.conv.weight"])
     ctx = None
     if save:
         ctx = _BlockCtx()

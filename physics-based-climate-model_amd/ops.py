@@ -3,6 +3,8 @@
 torch supplies device memory and the current HIP stream only; every function enqueues hand-written HIP kernels from
 libclimate_hip.so.  There is deliberately no CPU implementation here: calling these with CPU tensors raises.
 """
+import os
+
 import torch
 
 from ._lib import check, lib
@@ -147,22 +149,39 @@ def conv3x3_split(x0, wps, cout, x1=None, bias=None, resid=None, out=None, confi
     return out
 
 
-def wgrad3x3(x0, dy, g, c_off=0, x1=None, config=-1):
-    """g[cout][9][ctot] += wgrad(cat(x0, x1), dy) for input-channel range [c_off, ...)."""
+WGRAD_BF16X6 = os.environ.get("CM_WGRAD_BF16X6", "1") != "0"
+
+
+def _wgrad_call(x0, dy, g, c_off, x1, config):
+    """One launch of either weight-gradient family: ids >= SPLIT_BASE select the bf16x6 kernel (cm_wgrad3x3_split)."""
     n, c0, h, w = x0.shape
     c1 = 0 if x1 is None else x1.shape[1]
     cout, ctot = g.shape[0], g.shape[2]
     st1 = 0 if x1 is None else x1.stride(0)
+    fn = lib.cm_wgrad3x3_split if config >= SPLIT_BASE else lib.cm_wgrad3x3
+    cfg = config - SPLIT_BASE if config >= SPLIT_BASE else config
+    return fn(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(dy), dy.stride(0), _p(g), ctot, c_off, n, h, w, cout, cfg,
+              _stream())
+
+
+def wgrad3x3(x0, dy, g, c_off=0, x1=None, config=-1):
+    """g[cout][9][ctot] += wgrad(cat(x0, x1), dy) for input-channel range [c_off, ...).
+
+    With config < 0 the autotuner times the fp32-MFMA and (unless CM_WGRAD_BF16X6=0) the bf16x6 configurations on this
+    call signature and keeps the fastest."""
+    n, c0, h, w = x0.shape
+    c1 = 0 if x1 is None else x1.shape[1]
+    cout = g.shape[0]
     if config < 0:
         def launch(cfg, _scratch=[None]):
             if _scratch[0] is None:
                 _scratch[0] = torch.empty_like(g)
-            return lib.cm_wgrad3x3(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(dy), dy.stride(0), _p(_scratch[0]),
-                                   ctot, c_off, n, h, w, cout, cfg, _stream())
+            return _wgrad_call(x0, dy, _scratch[0], c_off, x1, cfg)
         cands = [c + (u << 8) for c in range(lib.cm_wgrad3x3_num_configs()) for u in (2, 3, 4, 6, 8)]
-        config = _pick(("wgrad3x3", n, h, w, c0, c1, cout), cands, launch, -1)
-    check(lib.cm_wgrad3x3(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(dy),
-                          dy.stride(0), _p(g), ctot, c_off, n, h, w, cout, config, _stream()), "wgrad3x3")
+        if WGRAD_BF16X6 and (c1 == 0 or c0 % 32 == 0):
+            cands += [SPLIT_BASE + c + (u << 8) for c in range(lib.cm_wgrad3x3_split_num_configs()) for u in (2, 4, 8)]
+        config = _pick(("wgrad3x3", n, h, w, c0, c1, cout, WGRAD_BF16X6), cands, launch, -1)
+    check(_wgrad_call(x0, dy, g, c_off, x1, config), "wgrad3x3")
     return g
 
 
@@ -222,6 +241,24 @@ def spatial_gate_fwd(a2, s, w7):
     return out, fmap, gate
 
 
+def se_spatial_gate_fwd(a2, pooled, w1, w2, w7):
+    """SE excite + spatial gate of one ConvBlock (src/unet.py:45-47) in two launches; returns out, z, s, fmap, gate."""
+    n, c, h, w = a2.shape
+    cr = w1.shape[0]
+    dev = a2.device
+    z = torch.empty(n, cr, device=dev, dtype=torch.float32)
+    s = torch.empty(n, c, device=dev, dtype=torch.float32)
+    fmap = torch.empty(n, 2, h, w, device=dev, dtype=torch.float32)
+    gate = torch.empty(n, h, w, device=dev, dtype=torch.float32)
+    out = torch.empty_like(_contig(a2))
+    st = _stream()
+    check(lib.cm_se_spatial_stats(_p(pooled), _p(_contig(w1)), _p(_contig(w2)), _p(a2), _p(z), _p(s), _p(fmap), n, c, cr,
+                                  h * w, st), "se_spatial_stats")
+    check(lib.cm_spatial_apply(_p(a2), _p(s), _p(fmap), _p(_contig(w7)), _p(gate), _p(out), n, c, h, w, st),
+          "spatial_apply")
+    return out, z, s, fmap, gate
+
+
 def gates_bwd(dout, a2, s, z, pooled, gate, fmap, w1, w2, w7, dw1, dw2, dw7):
     """Backward of SE + spatial gate up to (but excluding) the GroupNorm; returns the maps cm_gn_silu_bwd_gated needs."""
     n, c, h, w = a2.shape
@@ -234,10 +271,12 @@ def gates_bwd(dout, a2, s, z, pooled, gate, fmap, w1, w2, w7, dw1, dw2, dw7):
     dsig = torch.empty(n, c, device=dev, dtype=torch.float32)
     dz = torch.empty(n, cr, device=dev, dtype=torch.float32)
     dpool = torch.empty(n, c, device=dev, dtype=torch.float32)
+    c7ws = torch.empty(int(lib.cm_conv7_bwd_scratch_elems(n, h)), device=dev, dtype=torch.float32)
     st = _stream()
     check(lib.cm_gate_bwd_reduce(_p(_contig(dout)), _p(a2), _p(s), _p(gate), _p(fmap), _p(dgpre), _p(cnt), n, c, h * w,
                                  st), "gate_bwd_reduce")
-    check(lib.cm_conv7_bwd(_p(dgpre), _p(fmap), _p(_contig(w7)), _p(dmap), _p(dw7), n, h, w, st), "conv7_bwd")
+    check(lib.cm_conv7_bwd(_p(dgpre), _p(fmap), _p(_contig(w7)), _p(dmap), _p(dw7),
+                           _p(c7ws), n, h, w, st), "conv7_bwd")
     check(lib.cm_se_bwd_reduce(_p(dout), _p(a2), _p(s), _p(gate), _p(dmap), _p(fmap), _p(cnt), _p(ds), n, c, h * w, st),
           "se_bwd_reduce")
     check(lib.cm_se_excite_bwd(_p(ds), _p(s), _p(z), _p(pooled), _p(_contig(w1)), _p(_contig(w2)), _p(dsig), _p(dz),

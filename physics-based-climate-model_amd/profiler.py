@@ -40,6 +40,7 @@ MODELS = {
     "cm_conv3x3": (_conv_flops, _conv_bytes),
     "cm_conv3x3_split": (_conv_flops, _conv_bytes),     # same argument positions; ALGORITHMIC flops (x6 are executed)
     "cm_wgrad3x3": (_wgrad_flops, _wgrad_bytes),
+    "cm_wgrad3x3_split": (_wgrad_flops, _wgrad_bytes),  # same argument positions; ALGORITHMIC flops
     "cm_lstm_gates_fwd": (None, _lstm_fwd_bytes),
     "cm_lstm_gates_bwd": (None, _lstm_bwd_bytes),
 }
@@ -52,7 +53,7 @@ class KernelTimer:
         self.records = []
 
     def wrap(self, name, fn):
-        if name in ("cm_version", "cm_arch") or "pick_config" in name or "num_configs" in name or "packed_elems" in name:
+        if name in ("cm_version", "cm_arch") or "pick_config" in name or "num_configs" in name or "packed_elems" in name or "scratch_elems" in name:
             return fn
 
         def timed(*a):

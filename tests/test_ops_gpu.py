@@ -138,6 +138,51 @@ def test_wgrad3x3_all_configs(ops, case):
         assert dw[:, :4].abs().max().item() == 0.0
 
 
+WGS_CASES = WG_CASES + [
+    (9, 32, 32, 40, 12, 18),     # virtual concat, two sample groups (8 + 1)
+    (17, 64, 0, 64, 6, 9),       # three sample groups, two cout tiles
+    (4, 32, 64, 32, 24, 36),     # concat with unequal halves, column segments
+    (1, 3, 0, 8, 5, 7),          # everything ragged
+]
+
+
+@pytest.mark.parametrize("case", WGS_CASES)
+def test_wgrad3x3_split_all_configs(ops, case):
+    """bf16x6 weight gradient (cm_wgrad3x3_split): every tile configuration and grid size vs float64 autograd."""
+    from climate_amd._lib import lib
+    n, c0, c1, cout, h, w = case
+    if c1 and c0 % 32:
+        pytest.skip("virtual concat needs a 32-aligned first input")
+    x0 = rnd(n, c0, h, w, seed=11)
+    x1 = rnd(n, c1, h, w, seed=12) if c1 else None
+    dy = rnd(n, cout, h, w, seed=13)
+    xin = x0 if x1 is None else torch.cat([x0, x1], 1)
+    wt = torch.zeros(cout, c0 + c1, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xin.double(), wt, padding=1).backward(dy.double())
+    ctot = c0 + c1 + 4
+    for i in range(lib.cm_wgrad3x3_split_num_configs()):
+        for rounds4 in (0, 1, 8):
+            cfg = ops.SPLIT_BASE + i + (rounds4 << 8)
+            g = torch.zeros(cout, 9, ctot, device="cuda")
+            ops.wgrad3x3(dev(x0), dev(dy), g, c_off=4, x1=None if x1 is None else dev(x1), config=cfg)
+            dw = ops.wgrad3x3_unpack(g)
+            err = rel_l2(dw[:, 4:], wt.grad)
+            assert err < 2e-6, f"config {i}/{rounds4}: {err}"     # fp32-equivalent: far inside the 1e-4 parity bound
+            assert dw[:, :4].abs().max().item() == 0.0
+
+
+def test_wgrad3x3_split_strided_samples(ops):
+    """Time-slice views ([B,T,...] buffers, sample stride T*C*H*W) feed the bf16x6 weight gradient without copies."""
+    b, t, c, cout, h, w = 10, 3, 32, 32, 6, 9
+    xs = rnd(b, t, c, h, w, seed=21)
+    dys = rnd(b, t, cout, h, w, seed=22)
+    wt = torch.zeros(cout, c, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xs[:, 1].double(), wt, padding=1).backward(dys[:, 2].double())
+    g = torch.zeros(cout, 9, c, device="cuda")
+    ops.wgrad3x3(dev(xs)[:, 1], dev(dys)[:, 2], g, config=ops.SPLIT_BASE + 0)
+    assert rel_l2(ops.wgrad3x3_unpack(g), wt.grad) < 2e-6
+
+
 # --------------------------------------------------------------------------------------------- GN + SiLU
 @pytest.mark.parametrize("shape", [(3, 16, 6, 9), (2, 32, 16, 24), (2, 8, 12, 18), (1, 64, 48, 72)])
 def test_gn_silu(ops, shape):
@@ -217,6 +262,53 @@ def test_conv_block_chain_golden(ops):
     assert rel_l2(dx, g["dx"]) < TOL
     for k in G:
         assert rel_l2(G[k], g["g." + k]) < TOL, k
+
+
+@pytest.mark.parametrize("shape", [(6, 32, 48, 72), (5, 128, 12, 18), (7, 256, 6, 9), (3, 16, 10, 7), (6, 128, 1, 2),
+                                   (2, 8, 1, 1)])
+def test_fused_se_stats_equals_separate_launches(ops, shape):
+    """cm_se_spatial_stats == cm_se_excite_fwd + cm_spatial_stats bit for bit; spatial_apply at every vector width."""
+    n, c, h, w = shape
+    torch.manual_seed(3)
+    a2 = torch.randn(n, c, h, w, device="cuda")
+    pooled = a2.mean((2, 3))
+    cr = max(1, c // 8)
+    w1 = torch.randn(cr, c, 1, 1, device="cuda") * 0.3
+    w2 = torch.randn(c, cr, 1, 1, device="cuda") * 0.3
+    w7 = torch.randn(1, 2, 7, 7, device="cuda") * 0.1
+    z0, s0 = ops.se_excite_fwd(pooled, w1, w2)
+    out0, fmap0, gate0 = ops.spatial_gate_fwd(a2, s0, w7)
+    out1, z1, s1, fmap1, gate1 = ops.se_spatial_gate_fwd(a2, pooled, w1, w2, w7)
+    for a, b in ((z0, z1), (s0, s1), (fmap0, fmap1), (gate0, gate1), (out0, out1)):
+        assert torch.equal(a, b)
+    # against torch
+    u = a2 * s0[:, :, None, None]
+    m = torch.cat([u.mean(1, keepdim=True), u.amax(1, keepdim=True)], 1)
+    ref = u * torch.sigmoid(F.conv2d(m, w7, padding=3))
+    assert rel_l2(out1, ref) < TOL
+
+
+def test_conv7_bwd_many_workgroups(ops):
+    """conv7 backward at the benchmark width (1152-row partial table + fold), accumulating over repeated launches."""
+    torch.manual_seed(4)
+    n, h, w = 64, 48, 72
+    dgpre = torch.randn(n, h, w, device="cuda")
+    fmap = torch.randn(n, 2, h, w, device="cuda")
+    w7 = torch.randn(1, 2, 7, 7, device="cuda")
+    from climate_amd._lib import lib, check
+    dw7 = torch.zeros(98, device="cuda")
+    dmap = torch.empty(n, 2, h, w, device="cuda")
+    scr = torch.empty(int(lib.cm_conv7_bwd_scratch_elems(n, h)), device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        check(lib.cm_conv7_bwd(dgpre.data_ptr(), fmap.data_ptr(), w7.data_ptr(), dmap.data_ptr(), dw7.data_ptr(),
+                               scr.data_ptr(), n, h, w, st), "conv7_bwd")
+    fm = fmap.clone().requires_grad_(True)
+    wt = w7.clone().requires_grad_(True)
+    F.conv2d(fm, wt, padding=3).backward(dgpre[:, None])
+    assert rel_l2(dw7 / 3.0, wt.grad.reshape(-1)) < 1e-5
+    dm_ref = torch.autograd.grad(F.conv2d(fm, w7, padding=3), fm, dgpre[:, None])[0]
+    assert rel_l2(dmap, dm_ref) < 1e-5
 
 
 def test_gates_ties_backward(ops):

@@ -44,10 +44,15 @@ def main():
     ap.add_argument("--T", type=int, default=6)
     ap.add_argument("--what", default="both")
     ap.add_argument("--split", action="store_true", help="also time the bf16x6 kernel on the forward shapes")
+    ap.add_argument("--only", default="", help="comma-separated layer names (default: all)")
+    ap.add_argument("--skip-fp32", action="store_true", help="with --split: time only the bf16x6 kernels")
     args = ap.parse_args()
+    only = set(filter(None, args.only.split(",")))
     st = torch.cuda.current_stream().cuda_stream
     tot = {"conv": 0.0, "dgrad": 0.0, "wgrad": 0.0}
     for name, n, c0, c1, co, h, w in layers(args.base, args.B, args.T):
+        if only and name not in only:
+            continue
         ci = c0 + c1
         x0 = torch.randn(n, c0, h, w, device="cuda")
         x1 = torch.randn(n, c1, h, w, device="cuda") if c1 else None
@@ -96,14 +101,26 @@ def main():
         if args.what in ("wgrad", "both"):
             g = torch.zeros(co, 9, ci, device="cuda")
             res = []
-            for cfg in range(lib.cm_wgrad3x3_num_configs()):
+            for cfg in range(0 if args.skip_fp32 else lib.cm_wgrad3x3_num_configs()):
                 for upb in (2, 3, 4, 6, 8):
                     t = timeit(lambda: ops.wgrad3x3(x0, dy, g, x1=x1, config=cfg + (upb << 8)))
                     res.append((t, f"{cfg}/{upb}"))
             res.sort()
-            tot["wgrad"] += res[0][0]
+            res = res or [(float("inf"), "-")]
+            tot["wgrad"] += res[0][0] if res[0][1] != "-" else 0.0
             print(f"wgrad {name:8s} N={n:3d} {ci:3d}->{co:3d} @{h}x{w}: best cfg {res[0][1]:>5s} {res[0][0]:7.1f} us "
                   f"{flops / res[0][0] / 1e6:6.1f} TF | " + " ".join(f"{c}:{t:.0f}" for t, c in res[1:5]))
+            if args.split and (x1 is None or x0.shape[1] % 32 == 0):
+                res = []
+                for cfg in range(lib.cm_wgrad3x3_split_num_configs()):
+                    for upb in (2, 4, 8):
+                        t = timeit(lambda: ops.wgrad3x3(x0, dy, g, x1=x1, config=ops.SPLIT_BASE + cfg + (upb << 8)))
+                        res.append((t, f"{cfg}/{upb}"))
+                res.sort()
+                tot.setdefault("wgrad_split", 0.0)
+                tot["wgrad_split"] += res[0][0]
+                print(f"wgs   {name:8s} N={n:3d} {ci:3d}->{co:3d} @{h}x{w}: best cfg {res[0][1]:>5s} {res[0][0]:7.1f} us "
+                      f"{flops / res[0][0] / 1e6:6.1f} TF | " + " ".join(f"{c}:{t:.0f}" for t, c in res[1:6]))
     print("sum of best (us):", {k: round(v, 1) for k, v in tot.items()}, "(lstm.h counted once; it runs T-1 times)")
 
 
