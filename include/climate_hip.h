@@ -51,7 +51,8 @@ int cm_conv3x3(const float* in0, long long st0, int c0, const float* in1, long l
  * Same contract as cm_conv3x3 (same reference call sites), operands split into three bf16 pieces each, six bf16
  * MFMAs per 16-deep k-step, fp32 accumulation.  wps comes from cm_pack_conv3x3_split_batch (descriptor records as
  * cm_pack_conv3x3_batch, with the wp field pointing at cm_conv3x3_split_packed_bytes() bytes).  When in1 is given,
- * c0 must be a multiple of 16.  config in [0, cm_conv3x3_split_num_configs()).                                    */
+ * c0 must be a multiple of 16.  config bits 0-7 in [0, cm_conv3x3_split_num_configs()), bits 8.. = K split (as in
+ * cm_conv3x3: the output is zeroed and accumulated with float atomics; not with an in-place residual).         */
 int cm_conv3x3_split_num_configs(void);
 long long cm_conv3x3_split_packed_bytes(int k_channels, int out_channels);
 int cm_pack_conv3x3_split_batch(const void* descs_dev, int ndesc, int total_blocks, cm_stream stream);
@@ -106,19 +107,24 @@ int cm_spatial_stats(const float* a2, const float* s, float* map, int n, int c, 
 /* cm_se_excite_fwd + cm_spatial_stats in one launch (same results bit for bit): z [n,cr], s [n,c], map [n,2,hw]. */
 int cm_se_spatial_stats(const float* pooled, const float* w1, const float* w2, const float* a2, float* z, float* s,
                         float* map, int n, int c, int cr, int hw, cm_stream stream);
+/* pooled (nullable, [n,c,h/2,w/2], h and w even): also writes nn.MaxPool2d(2) of `out` (the encoder's Down input,
+ * src/unet_convlstm_attention.py:21,25) from the same pass. */
 int cm_spatial_apply(const float* a2, const float* s, const float* map, const float* w7, float* gate, float* out,
-                     int n, int c, int h, int w, cm_stream stream);
+                     float* pooled, int n, int c, int h, int w, cm_stream stream);
 /* backward chain: gate_bwd_reduce -> conv7_bwd -> se_bwd_reduce -> se_excite_bwd -> cm_gn_silu_bwd_gated */
 int cm_gate_bwd_reduce(const float* dout, const float* a2, const float* s, const float* gate, const float* map,
                        float* dgpre, float* cnt, int n, int c, int hw, cm_stream stream);
 /* `scratch`: cm_conv7_bwd_scratch_elems(n, h) floats of workspace (per-workgroup partial dW7 sums, no initialisation
  * needed): thousands of workgroups adding into the same 98 addresses serialise in the L2, so the partials are stored
- * and folded by a second tiny kernel inside the same call. */
+ * and folded by a second tiny kernel inside the same call, or -- with dw7 = NULL -- by the following cm_se_bwd_reduce. */
 long long cm_conv7_bwd_scratch_elems(int n, int h);
 int cm_conv7_bwd(const float* dgpre, const float* map, const float* w7, float* dmap, float* dw7 /* accumulated */,
                  float* scratch, int n, int h, int w, cm_stream stream);
+/* c7_partials (nullable): the scratch of a preceding cm_conv7_bwd(..., dw7 = NULL, ...) with c7_rows =
+ * n * ceil(h/8) rows; the first workgroups then also fold those partial sums into dw7 (saves the fold launch). */
 int cm_se_bwd_reduce(const float* dout, const float* a2, const float* s, const float* gate, const float* dmap,
-                     const float* map, const float* cnt, float* ds, int n, int c, int hw, cm_stream stream);
+                     const float* map, const float* cnt, float* ds, int n, int c, int hw, const float* c7_partials,
+                     int c7_rows, float* dw7, cm_stream stream);
 /* dsig [n,c], dz [n,cr], dpool [n,c] are outputs; dw1 [cr,c], dw2 [c,cr] are ACCUMULATED. */
 int cm_se_excite_bwd(const float* ds, const float* s, const float* z, const float* pooled, const float* w1,
                      const float* w2, float* dsig, float* dz, float* dpool, float* dw1, float* dw2, int n, int c,
@@ -140,8 +146,9 @@ int cm_convT2x2_fwd(const float* x, long long sx, const float* w, const float* b
                     int ci, int co, int h, int w_, cm_stream stream);
 int cm_convT2x2_bwd_data(const float* dy, long long sdy, const float* w, float* dx, long long sdx, int n, int ci,
                          int co, int h, int w_, cm_stream stream);
-int cm_convT2x2_bwd_weight(const float* x, long long sx, const float* dy, long long sdy, float* dw /* accumulated */,
-                           int n, int ci, int co, int h, int w_, cm_stream stream);
+/* dw [ci,co,2,2] and (nullable) db [co] are ACCUMULATED. */
+int cm_convT2x2_bwd_weight(const float* x, long long sx, const float* dy, long long sdy, float* dw, float* db, int n,
+                           int ci, int co, int h, int w_, cm_stream stream);
 
 /* ---- ConvLSTM cell pointwise stage ------------------------------------------------------------------------- *
  * ConvLSTMCell.forward src/convlstm.py:14-19 (gate order i,f,o,g).  gates [b,4ch,hw]: pre-activations in,

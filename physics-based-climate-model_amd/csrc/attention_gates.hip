@@ -203,12 +203,14 @@ __global__ __launch_bounds__(256) void se_spatial_stats_kernel(const float* __re
 // the band's pixels is computed once into LDS (XB adjacent pixels per thread share their 7x(XB+6) window reads), then
 // the band -- a contiguous run of BAND*W floats per channel -- is streamed with VEC-wide accesses.
 constexpr int GATE_BAND = 8;
-template <int VEC, int XB>
+// POOL: the band's rows are streamed in pairs and MaxPool2d(2) of `out` (src/unet_convlstm_attention.py:21,25) is
+// written next to it, which saves the pooling launch and its re-read of `out`.
+template <int VEC, int XB, bool POOL>
 __global__ __launch_bounds__(256) void spatial_apply_kernel(const float* __restrict__ a2, const float* __restrict__ s,
                                                              const float* __restrict__ map,
                                                              const float* __restrict__ w7, float* __restrict__ gate,
-                                                             float* __restrict__ out, int C, int H, int W,
-                                                             int c_per_split) {
+                                                             float* __restrict__ out, float* __restrict__ pooled,
+                                                             int C, int H, int W, int c_per_split) {
   constexpr int BAND = GATE_BAND;
   extern __shared__ float sh[];
   const int PW = W + 6 + 4;                    // row pitch of the padded map tile (room for the XB <= 4 overshoot)
@@ -258,9 +260,36 @@ __global__ __launch_bounds__(256) void spatial_apply_kernel(const float* __restr
     for (int i = tid; i < npx; i += 256) gate[(long long)n * HW + y0 * W + i] = gsh[i];
   const int c0 = blockIdx.z * c_per_split;
   const int nc = min(C, c0 + c_per_split) - c0;
-  const int nv = npx / VEC;                    // host guarantees npx % VEC == 0 and aligned bases
   const float* sp = s + (long long)n * C;
   typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  if constexpr (POOL) {                        // host guarantees even rows, W % VEC == 0, VEC in {2, 4}
+    const int wv = W / VEC, nvp = (rows / 2) * wv, Wo = W / 2;
+    const unsigned magic = 0xFFFFFFFFu / (unsigned)max(nvp, 1) + 1u;
+    for (int i = tid; i < nc * nvp; i += 256) {
+      const int q = nvp == 1 ? i : (int)__umulhi((unsigned)i, magic);
+      const int c = c0 + q, v = i - q * nvp;
+      const int rp = v / wv, xv = v - rp * wv;
+      const int g0 = (2 * rp) * W + xv * VEC;
+      const long long off = ((long long)n * C + c) * HW + y0 * W + g0;
+      const float sc = sp[c];
+      const vec_t a0 = *reinterpret_cast<const vec_t*>(a2 + off);
+      const vec_t a1 = *reinterpret_cast<const vec_t*>(a2 + off + W);
+      vec_t o0, o1;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        o0[e] = (a0[e] * sc) * gsh[g0 + e];
+        o1[e] = (a1[e] * sc) * gsh[g0 + W + e];
+      }
+      *reinterpret_cast<vec_t*>(out + off) = o0;
+      *reinterpret_cast<vec_t*>(out + off + W) = o1;
+      float* pp = pooled + (((long long)n * C + c) * (H / 2) + y0 / 2 + rp) * Wo + xv * (VEC / 2);
+#pragma unroll
+      for (int e = 0; e < VEC / 2; ++e)
+        pp[e] = fmaxf(fmaxf(o0[2 * e], o0[2 * e + 1]), fmaxf(o1[2 * e], o1[2 * e + 1]));
+    }
+    return;
+  }
+  const int nv = npx / VEC;                    // host guarantees npx % VEC == 0 and aligned bases
   const unsigned magic = 0xFFFFFFFFu / (unsigned)max(nv, 1) + 1u;   // i / nv == umulhi(i, magic) for i*nv < 2^32
   for (int i = tid; i < nc * nv; i += 256) {
     const int q = nv == 1 ? i : (int)__umulhi((unsigned)i, magic);   // (magic overflows to 0 for nv == 1)
@@ -410,8 +439,8 @@ __global__ __launch_bounds__(256) void conv7_bwd_kernel(const float* __restrict_
 }
 
 // dw7[tap] += sum_rows partials[row][tap]; workgroup b takes rows [b*rpb, (b+1)*rpb), two row-interleaved halves
-__global__ __launch_bounds__(256) void conv7_fold_kernel(const float* __restrict__ partials, int nrows, int rpb,
-                                                          float* __restrict__ dw7) {
+__device__ __forceinline__ void conv7_fold(const float* __restrict__ partials, int nrows, int rpb,
+                                           float* __restrict__ dw7) {
   __shared__ float sh[128];
   const int tap = threadIdx.x & 127, hs = threadIdx.x >> 7;
   const int r0 = blockIdx.x * rpb, r1 = min(nrows, r0 + rpb);
@@ -429,6 +458,11 @@ __global__ __launch_bounds__(256) void conv7_fold_kernel(const float* __restrict
   if (hs == 0 && tap < 98) unsafeAtomicAdd(dw7 + tap, (a0 + a1) + sh[tap]);
 }
 
+__global__ __launch_bounds__(256) void conv7_fold_kernel(const float* __restrict__ partials, int nrows, int rpb,
+                                                          float* __restrict__ dw7) {
+  conv7_fold(partials, nrows, rpb, dw7);
+}
+
 // ds[n,c] = sum_p dU * a2, with dU = dout*gate + dmapA/C + dmapM*[U==max]/cnt.  One wave per (n,c), VEC pixels per lane
 // and load.
 template <int VEC>
@@ -439,8 +473,12 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const float* __restr
                                                              const float* __restrict__ dmap,
                                                              const float* __restrict__ map,
                                                              const float* __restrict__ cnt, float* __restrict__ ds,
-                                                             int NC, int C, int HW) {
+                                                             int NC, int C, int HW,
+                                                             const float* __restrict__ c7_partials, int c7_rows,
+                                                             int c7_rpb, float* __restrict__ dw7) {
   typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  // side duty of the first workgroups: fold the preceding cm_conv7_bwd's per-workgroup dW7 partials (saves a launch)
+  if (c7_partials && blockIdx.x * c7_rpb < c7_rows) conv7_fold(c7_partials, c7_rows, c7_rpb, dw7);
   const int lane = threadIdx.x & 63;
   const int nc = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (nc >= NC) return;
@@ -512,8 +550,8 @@ int cm_se_spatial_stats(const float* pooled, const float* w1, const float* w2, c
 }
 
 int cm_spatial_apply(const float* a2, const float* s, const float* map, const float* w7, float* gate, float* out,
-                     int n, int c, int h, int w, cm_stream stream) {
-  if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return -22;
+                     float* pooled, int n, int c, int h, int w, cm_stream stream) {
+  if (n <= 0 || c <= 0 || h <= 0 || w <= 0 || (pooled && ((h | w) & 1))) return -22;
   const int hw = h * w, bands = cdiv(h, GATE_BAND);
   const size_t lds = (size_t)(2 * (GATE_BAND + 6) * (w + 10) + GATE_BAND * w) * sizeof(float);
   if (lds > 60 * 1024) return -22;  // W up to ~400
@@ -525,13 +563,24 @@ int cm_spatial_apply(const float* a2, const float* s, const float* map, const fl
   const int last = (h - (bands - 1) * GATE_BAND) * w;
   const bool al = (((uintptr_t)a2 | (uintptr_t)out) & 15) == 0;
   const int band_px = GATE_BAND * w;
-  const int vec = (al && hw % 4 == 0 && band_px % 4 == 0 && last % 4 == 0)   ? 4
-                  : (al && hw % 2 == 0 && band_px % 2 == 0 && last % 2 == 0) ? 2
-                                                                             : 1;
+  int vec = (al && hw % 4 == 0 && band_px % 4 == 0 && last % 4 == 0)   ? 4
+            : (al && hw % 2 == 0 && band_px % 2 == 0 && last % 2 == 0) ? 2
+                                                                       : 1;
+  if (pooled) {
+    if (!al) return -22;
+    vec = (w % 4 == 0) ? 4 : 2;                     // row pairs: vectors must not straddle rows
+  }
   const int xb = w >= 64 ? 4 : (w >= 32 ? 2 : 1);   // gate phase: ~150 busy threads per band at every level
-#define CM_APPLY(V, X)                                                                                          \
-  if (vec == V && xb == X)                                                                                      \
-    spatial_apply_kernel<V, X><<<grid, 256, lds, (hipStream_t)stream>>>(a2, s, map, w7, gate, out, c, h, w, cps);
+#define CM_APPLY(V, X)                                                                                               \
+  if (vec == V && xb == X) {                                                                                         \
+    if (pooled && V > 1)                                                                                             \
+      spatial_apply_kernel<(V > 1 ? V : 2), X, true><<<grid, 256, lds, (hipStream_t)stream>>>(a2, s, map, w7, gate,  \
+                                                                                               out, pooled, c, h, w, \
+                                                                                               cps);                 \
+    else                                                                                                             \
+      spatial_apply_kernel<V, X, false><<<grid, 256, lds, (hipStream_t)stream>>>(a2, s, map, w7, gate, out, nullptr, \
+                                                                                 c, h, w, cps);                      \
+  }
   CM_APPLY(4, 4) CM_APPLY(4, 2) CM_APPLY(4, 1) CM_APPLY(2, 4) CM_APPLY(2, 2) CM_APPLY(2, 1) CM_APPLY(1, 4)
   CM_APPLY(1, 2) CM_APPLY(1, 1)
 #undef CM_APPLY
@@ -552,6 +601,11 @@ long long cm_conv7_bwd_scratch_elems(int n, int h) {
   return (n <= 0 || h <= 0) ? -22 : (long long)n * cdiv(h, 8) * 98;
 }
 
+static void conv7_fold_split(int nrows, int* fb, int* rpb) {
+  *fb = max(1, min(8, nrows / 32));
+  *rpb = cdiv(nrows, *fb);
+}
+
 int cm_conv7_bwd(const float* dgpre, const float* map, const float* w7, float* dmap, float* dw7, float* scratch, int n,
                  int h, int w, cm_stream stream) {
   if (n <= 0 || h <= 0 || w <= 0 || !scratch) return -22;
@@ -561,24 +615,34 @@ int cm_conv7_bwd(const float* dgpre, const float* map, const float* w7, float* d
   const int bands = cdiv(h, BAND), nrows = bands * n;
   conv7_bwd_kernel<BAND><<<dim3(bands, n), 256, lds, (hipStream_t)stream>>>(dgpre, map, w7, dmap, scratch, h, w);
   CM_CHECK_LAUNCH();
-  const int fb = max(1, min(8, nrows / 32)), rpb = cdiv(nrows, fb);
-  conv7_fold_kernel<<<cdiv(nrows, rpb), 256, 0, (hipStream_t)stream>>>(scratch, nrows, rpb, dw7);
-  CM_CHECK_LAUNCH();
+  if (dw7) {
+    int fb, rpb;
+    conv7_fold_split(nrows, &fb, &rpb);
+    conv7_fold_kernel<<<cdiv(nrows, rpb), 256, 0, (hipStream_t)stream>>>(scratch, nrows, rpb, dw7);
+    CM_CHECK_LAUNCH();
+  }
   return 0;
 }
 
 int cm_se_bwd_reduce(const float* dout, const float* a2, const float* s, const float* gate, const float* dmap,
-                     const float* map, const float* cnt, float* ds, int n, int c, int hw, cm_stream stream) {
-  if (n <= 0 || c <= 0 || hw <= 0) return -22;
+                     const float* map, const float* cnt, float* ds, int n, int c, int hw, const float* c7_partials,
+                     int c7_rows, float* dw7, cm_stream stream) {
+  if (n <= 0 || c <= 0 || hw <= 0 || (c7_partials && (c7_rows <= 0 || !dw7))) return -22;
   const unsigned grid = (unsigned)cdiv((long long)n * c, 4);
+  int fb = 1, rpb = 0;
+  if (c7_partials) {
+    conv7_fold_split(c7_rows, &fb, &rpb);
+    if ((unsigned)cdiv(c7_rows, rpb) > grid) return -22;
+  }
   const bool al = (((uintptr_t)dout | (uintptr_t)a2 | (uintptr_t)gate | (uintptr_t)dmap | (uintptr_t)map |
                     (uintptr_t)cnt) & 15) == 0;
-  if (al && hw % 4 == 0)
-    se_bwd_reduce_kernel<4><<<grid, 256, 0, (hipStream_t)stream>>>(dout, a2, s, gate, dmap, map, cnt, ds, n * c, c, hw);
-  else if (al && hw % 2 == 0)
-    se_bwd_reduce_kernel<2><<<grid, 256, 0, (hipStream_t)stream>>>(dout, a2, s, gate, dmap, map, cnt, ds, n * c, c, hw);
-  else
-    se_bwd_reduce_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(dout, a2, s, gate, dmap, map, cnt, ds, n * c, c, hw);
+#define CM_SEBR(V)                                                                                                  \
+  se_bwd_reduce_kernel<V><<<grid, 256, 0, (hipStream_t)stream>>>(dout, a2, s, gate, dmap, map, cnt, ds, n * c, c, hw, \
+                                                                 c7_partials, c7_rows, rpb, dw7)
+  if (al && hw % 4 == 0) CM_SEBR(4);
+  else if (al && hw % 2 == 0) CM_SEBR(2);
+  else CM_SEBR(1);
+#undef CM_SEBR
   CM_CHECK_LAUNCH();
   return 0;
 }

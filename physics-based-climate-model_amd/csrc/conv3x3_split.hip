@@ -35,6 +35,7 @@ struct SplitArgs {
   float* out;
   long long sto;
   int N, H, W, Cout, CoutP, nsteps, tiles_x, tiles_y;   // nsteps = 16-channel k-steps (= LDS stages)
+  int ksplit;  // > 1: blockIdx.z owns a share of the k-steps and accumulates into a pre-zeroed output with atomics
 };
 
 template <int TH, int TW, int S, int WAVES, int NPT, int WM, bool DUAL>
@@ -184,11 +185,14 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_split_kernel(SplitArgs a) 
 
   const int wlane = half * BCO + l31;
 
-  load_chunk(0);
-  for (int chunk = 0; chunk < nsteps; ++chunk) {
+  const int cps = (nsteps + a.ksplit - 1) / a.ksplit;
+  const int c_begin = blockIdx.z * cps, c_end = min(nsteps, c_begin + cps);
+  if (c_begin >= c_end) return;
+  load_chunk(c_begin);
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
     store_chunk();
     __syncthreads();
-    if (chunk + 1 < nsteps) load_chunk(chunk + 1);
+    if (chunk + 1 < c_end) load_chunk(chunk + 1);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       bf16x8 bf[3][NPT];
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_split_kernel(SplitArgs a) 
   }
 
   // ---- epilogue (same accumulator map as the fp32 kernel) ----
-  if (a.bias) {
+  if (a.bias && blockIdx.z == 0) {
 #pragma unroll
     for (int m = 0; m < WM; ++m) {
       float bv[16];
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_split_kernel(SplitArgs a) 
         for (int r = 0; r < 16; ++r) acc[m][p][r] += bv[r];
     }
   }
-  if (a.resid) {
+  if (a.resid && blockIdx.z == 0) {
 #pragma unroll
     for (int m = 0; m < WM; ++m)
 #pragma unroll
@@ -258,7 +262,12 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_split_kernel(SplitArgs a) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (co < a.Cout) a.out[obase[p] + (long long)co * HW] = acc[m][p][r];
+          if (co < a.Cout) {
+            if (a.ksplit > 1)
+              unsafeAtomicAdd(a.out + obase[p] + (long long)co * HW, acc[m][p][r]);
+            else
+              a.out[obase[p] + (long long)co * HW] = acc[m][p][r];
+          }
         }
       }
     }
@@ -336,13 +345,26 @@ constexpr SCfg kS[] = {
 };
 constexpr int kNumS = sizeof(kS) / sizeof(kS[0]);
 
+__global__ void zero_out_split_kernel(float* __restrict__ out, long long sto, int n, long long per) {
+  const long long total = (long long)n * per;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+    out[(i / per) * sto + i % per] = 0.f;
+}
+
 template <int I, bool DUAL>
 int launch_s(const SplitArgs& a0, hipStream_t st) {
   constexpr SCfg c = kS[I];
   SplitArgs a = a0;
   a.tiles_x = cdiv(a.W, c.tw);
   a.tiles_y = cdiv(a.H, c.th);
-  dim3 grid(a.tiles_x * a.tiles_y * cdiv(a.N, c.s), cdiv(a.Cout, 32 * c.wm));
+  if (a.ksplit > a.nsteps) a.ksplit = a.nsteps;
+  if (a.ksplit < 1) a.ksplit = 1;
+  if (a.ksplit > 1) {
+    const long long per = (long long)a.Cout * a.H * a.W;
+    const long long zb = ((long long)a.N * per + 255) / 256;
+    zero_out_split_kernel<<<(int)(zb > 2048 ? 2048 : zb), 256, 0, st>>>(a.out, a.sto, a.N, per);
+  }
+  dim3 grid(a.tiles_x * a.tiles_y * cdiv(a.N, c.s), cdiv(a.Cout, 32 * c.wm), a.ksplit);
   conv3x3_split_kernel<c.th, c.tw, c.s, c.waves, c.npt, c.wm, DUAL><<<grid, c.waves * 64, 0, st>>>(a);
   CM_CHECK_LAUNCH();
   return 0;
@@ -406,6 +428,9 @@ int cm_conv3x3_split(const float* in0, long long st0, int c0, const float* in1, 
   a.N = n; a.H = h; a.W = w; a.Cout = cout;
   a.CoutP = ((cout + 31) / 32) * 32;
   a.nsteps = (c0 + c1 + SKC - 1) / SKC;
+  a.ksplit = config >> 8;                    // bits 8.. = K split over blockIdx.z (0/1 = none)
+  config &= 0xff;
+  if (a.ksplit > 1 && resid == out) return -22;   // the in-place residual would be zeroed
   a.tiles_x = a.tiles_y = 0;
   return c1 > 0 ? dispatch_s<true>(config, a, (hipStream_t)stream) : dispatch_s<false>(config, a, (hipStream_t)stream);
 }

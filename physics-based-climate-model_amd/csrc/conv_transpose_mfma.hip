@@ -133,8 +133,8 @@ __global__ __launch_bounds__(NWV * 64) void convT_mfma_kernel(const float* __res
 constexpr int WPX = 64;
 __global__ __launch_bounds__(256) void convT_wgrad_mfma_kernel(const float* __restrict__ x, long long sx,
                                                                 const float* __restrict__ dy, long long sdy,
-                                                                float* __restrict__ dw, int N, int Ci, int Co, int H,
-                                                                int W, int chunks_per_block) {
+                                                                float* __restrict__ dw, float* __restrict__ db, int N,
+                                                                int Ci, int Co, int H, int W, int chunks_per_block) {
   __shared__ float Xs[64][WPX + 1];
   __shared__ float Ds[64][WPX + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256) void convT_wgrad_mfma_kernel(const float* __re
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum = 0.f;
 
   // staging roles: X: 16 values per thread (pixel = tid%64, channels tid/64 + 4q); dY: 8 float2 per thread
   const int spx = tid & 63, sgrp = tid >> 6;
@@ -201,8 +202,22 @@ __global__ __launch_bounds__(256) void convT_wgrad_mfma_kernel(const float* __re
       const float b = Ds[wn * 32 + l31][2 * k2 + half];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
+    // bias gradient db[o] = sum dY: the input-channel tile 0 workgroups own it (their dY tile is already in LDS)
+    if (db && blockIdx.x == 0 && tid < 64) {
+      float t = 0.f;
+#pragma unroll 16
+      for (int k = 0; k < WPX; ++k) t += Ds[tid][k];   // row pitch WPX+1: conflict free
+      bsum += t;
+    }
   }
   if (ch0 >= ch1) return;
+  if (db && blockIdx.x == 0 && tid < 64) {
+    // the four taps of an output channel sit in four adjacent lanes
+    bsum += __shfl_xor(bsum, 1, 64);
+    bsum += __shfl_xor(bsum, 2, 64);
+    const int o = o0 + (tid >> 2);
+    if ((tid & 3) == 0 && o < Co) unsafeAtomicAdd(db + o, bsum);
+  }
   // D[i][j]: lane holds column j = l31, rows (r&3) + 8*(r>>2) + 4*half; dW row c is contiguous along j
   const int j = o0 * 4 + wn * 32 + l31;
 #pragma unroll
@@ -236,8 +251,8 @@ int cm_convT2x2_bwd_data(const float* dy, long long sdy, const float* w, float* 
   return 0;
 }
 
-int cm_convT2x2_bwd_weight(const float* x, long long sx, const float* dy, long long sdy, float* dw, int n, int ci,
-                           int co, int h, int w_, cm_stream stream) {
+int cm_convT2x2_bwd_weight(const float* x, long long sx, const float* dy, long long sdy, float* dw, float* db, int n,
+                           int ci, int co, int h, int w_, cm_stream stream) {
   if (n <= 0 || ci <= 0 || co <= 0 || h <= 0 || w_ <= 0 || (sdy & 1)) return -22;
   const long long nchunks = ((long long)n * h * w_ + WPX - 1) / WPX;
   const int gx = cdiv(ci, 64), gy = cdiv(co, 16);
@@ -246,7 +261,7 @@ int cm_convT2x2_bwd_weight(const float* x, long long sx, const float* dy, long l
   if (splits < 1) splits = 1;
   const int cpb = (int)((nchunks + splits - 1) / splits);
   convT_wgrad_mfma_kernel<<<dim3(gx, gy, (unsigned)((nchunks + cpb - 1) / cpb)), 256, 0, (hipStream_t)stream>>>(
-      x, sx, dy, sdy, dw, n, ci, co, h, w_, cpb);
+      x, sx, dy, sdy, dw, db, n, ci, co, h, w_, cpb);
   CM_CHECK_LAUNCH();
   return 0;
 }

@@ -164,19 +164,22 @@ def pack_weights(p: Params, need_input_grad: bool = False) -> Dict[str, Tensor]:
 
 
 # ------------------------------------------------------------------------------------------------- ConvBlock
-def _block_fwd(p: Params, pk, prefix: str, x0: Tensor, x1: Optional[Tensor], save: bool):
+def _block_fwd(p: Params, pk, prefix: str, x0: Tensor, x1: Optional[Tensor], save: bool, pool: bool = False):
     co = p[prefix + "body.0.weight"].shape[0]
     y1 = pk.conv(prefix + "body.0.weight/f", x0, co, x1=x1)
     a1, st1, _ = ops.gn_silu_fwd(y1, p[prefix + "body.1.weight"], p[prefix + "body.1.bias"])
     y2 = pk.conv(prefix + "body.3.weight/f", a1, co)
     a2, st2, pooled = ops.gn_silu_fwd(y2, p[prefix + "body.4.weight"], p[prefix + "body.4.bias"], want_pooled=True)
-    out, z, s, fmap, gate = ops.se_spatial_gate_fwd(a2, pooled, p[prefix + "se.fc.0.weight"],
-                                                    p[prefix + "se.fc.2.weight"], p[prefix + "spat.conv.weight"])
+    res = ops.se_spatial_gate_fwd(a2, pooled, p[prefix + "se.fc.0.weight"], p[prefix + "se.fc.2.weight"],
+                                  p[prefix + "spat.conv.weight"], pool_out=pool)
+    out, z, s, fmap, gate = res[:5]
     ctx = None
     if save:
         ctx = _BlockCtx()
         ctx.x0, ctx.x1, ctx.y1, ctx.a1, ctx.st1, ctx.y2, ctx.a2, ctx.st2 = x0, x1, y1, a1, st1, y2, a2, st2
         ctx.pooled, ctx.z, ctx.s, ctx.fmap, ctx.gate, ctx.out = pooled, z, s, fmap, gate, out
+    if pool:
+        return out, ctx, res[5]
     return out, ctx
 
 
@@ -280,12 +283,9 @@ def forward(p: Params, pk, x_seq: Tensor, save: bool = True):
     sv = Saved() if save else None
 
     # ---- encoder, all frames at once -------------------------------------------------------------------
-    s1, c1 = _block_fwd(p, pk, "enc1.", x, None, save)
-    p1 = ops.maxpool2_fwd(s1)
-    s2, c2 = _block_fwd(p, pk, "enc2.conv.", p1, None, save)
-    p2 = ops.maxpool2_fwd(s2)
-    s3, c3 = _block_fwd(p, pk, "enc3.conv.", p2, None, save)
-    p3 = ops.maxpool2_fwd(s3)
+    s1, c1, p1 = _block_fwd(p, pk, "enc1.", x, None, save, pool=True)     # Down = MaxPool2d(2) + ConvBlock
+    s2, c2, p2 = _block_fwd(p, pk, "enc2.conv.", p1, None, save, pool=True)
+    s3, c3, p3 = _block_fwd(p, pk, "enc3.conv.", p2, None, save, pool=True)
     s4, c4 = _block_fwd(p, pk, "enc4.conv.", p3, None, save)
 
     # ---- ConvLSTM bottleneck ---------------------------------------------------------------------------

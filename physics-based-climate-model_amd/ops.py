@@ -108,7 +108,9 @@ def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1, w
         cands = [c + ((k if k > 1 else 0) << 8) for c in range(lib.cm_conv3x3_num_configs()) for k in splits]
         use_split = wps is not None and (c1 == 0 or c0 % 16 == 0)
         if use_split:
-            cands += [SPLIT_BASE + c for c in range(lib.cm_conv3x3_split_num_configs())]
+            ssplits = [1] + [k for k in (2, 4) if (c0 + c1) // 16 >= 4 * k and len(splits) > 1]
+            cands += [SPLIT_BASE + c + ((k if k > 1 else 0) << 8) for c in range(lib.cm_conv3x3_split_num_configs())
+                      for k in ssplits]
         config = _pick(("conv3x3", n, h, w, c0, c1, cout, len(splits), use_split), cands, launch, -1)
     if config >= SPLIT_BASE:
         check(lib.cm_conv3x3_split(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(wps), _p(bias), _p(resid),
@@ -236,13 +238,14 @@ def spatial_gate_fwd(a2, s, w7):
     gate = torch.empty(n, h, w, device=a2.device, dtype=torch.float32)
     out = torch.empty_like(_contig(a2))
     check(lib.cm_spatial_stats(_p(a2), _p(s), _p(fmap), n, c, h * w, _stream()), "spatial_stats")
-    check(lib.cm_spatial_apply(_p(a2), _p(s), _p(fmap), _p(_contig(w7)), _p(gate), _p(out), n, c, h, w, _stream()),
-          "spatial_apply")
+    check(lib.cm_spatial_apply(_p(a2), _p(s), _p(fmap), _p(_contig(w7)), _p(gate), _p(out), None, n, c, h, w,
+                               _stream()), "spatial_apply")
     return out, fmap, gate
 
 
-def se_spatial_gate_fwd(a2, pooled, w1, w2, w7):
-    """SE excite + spatial gate of one ConvBlock (src/unet.py:45-47) in two launches; returns out, z, s, fmap, gate."""
+def se_spatial_gate_fwd(a2, pooled, w1, w2, w7, pool_out=False):
+    """SE excite + spatial gate of one ConvBlock (src/unet.py:45-47) in two launches; returns out, z, s, fmap, gate
+    (and MaxPool2d(2)(out) when ``pool_out``: the encoder's next input, written by the same pass)."""
     n, c, h, w = a2.shape
     cr = w1.shape[0]
     dev = a2.device
@@ -254,8 +257,11 @@ def se_spatial_gate_fwd(a2, pooled, w1, w2, w7):
     st = _stream()
     check(lib.cm_se_spatial_stats(_p(pooled), _p(_contig(w1)), _p(_contig(w2)), _p(a2), _p(z), _p(s), _p(fmap), n, c, cr,
                                   h * w, st), "se_spatial_stats")
-    check(lib.cm_spatial_apply(_p(a2), _p(s), _p(fmap), _p(_contig(w7)), _p(gate), _p(out), n, c, h, w, st),
+    mp = torch.empty(n, c, h // 2, w // 2, device=dev, dtype=torch.float32) if pool_out else None
+    check(lib.cm_spatial_apply(_p(a2), _p(s), _p(fmap), _p(_contig(w7)), _p(gate), _p(out), _p(mp), n, c, h, w, st),
           "spatial_apply")
+    if pool_out:
+        return out, z, s, fmap, gate, mp
     return out, z, s, fmap, gate
 
 
@@ -275,10 +281,10 @@ def gates_bwd(dout, a2, s, z, pooled, gate, fmap, w1, w2, w7, dw1, dw2, dw7):
     st = _stream()
     check(lib.cm_gate_bwd_reduce(_p(_contig(dout)), _p(a2), _p(s), _p(gate), _p(fmap), _p(dgpre), _p(cnt), n, c, h * w,
                                  st), "gate_bwd_reduce")
-    check(lib.cm_conv7_bwd(_p(dgpre), _p(fmap), _p(_contig(w7)), _p(dmap), _p(dw7),
-                           _p(c7ws), n, h, w, st), "conv7_bwd")
-    check(lib.cm_se_bwd_reduce(_p(dout), _p(a2), _p(s), _p(gate), _p(dmap), _p(fmap), _p(cnt), _p(ds), n, c, h * w, st),
-          "se_bwd_reduce")
+    # dW7 partials are folded by the first workgroups of se_bwd_reduce (one launch less than folding in conv7_bwd)
+    check(lib.cm_conv7_bwd(_p(dgpre), _p(fmap), _p(_contig(w7)), _p(dmap), None, _p(c7ws), n, h, w, st), "conv7_bwd")
+    check(lib.cm_se_bwd_reduce(_p(dout), _p(a2), _p(s), _p(gate), _p(dmap), _p(fmap), _p(cnt), _p(ds), n, c, h * w,
+                               _p(c7ws), c7ws.numel() // 98, _p(dw7), st), "se_bwd_reduce")
     check(lib.cm_se_excite_bwd(_p(ds), _p(s), _p(z), _p(pooled), _p(_contig(w1)), _p(_contig(w2)), _p(dsig), _p(dz),
                                _p(dpool), _p(dw1), _p(dw2), n, c, cr, st), "se_excite_bwd")
     return dmap, cnt, dpool
@@ -330,9 +336,8 @@ def convT2x2_bwd(x, w, dy, dw, db):
     st = _stream()
     check(lib.cm_convT2x2_bwd_data(_p(dy), dy.stride(0), _p(_contig(w)), _p(dx), dx.stride(0), n, ci, co, h, wd, st),
           "convT_bwd_data")
-    check(lib.cm_convT2x2_bwd_weight(_p(x), x.stride(0), _p(dy), dy.stride(0), _p(dw), n, ci, co, h, wd, st),
+    check(lib.cm_convT2x2_bwd_weight(_p(x), x.stride(0), _p(dy), dy.stride(0), _p(dw), _p(db), n, ci, co, h, wd, st),
           "convT_bwd_weight")
-    check(lib.cm_channel_sum(_p(dy), dy.stride(0), _p(db), n, co, 4 * h * wd, st), "convT_bias")
     return dx
 
 

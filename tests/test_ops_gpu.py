@@ -265,7 +265,7 @@ def test_conv_block_chain_golden(ops):
 
 
 @pytest.mark.parametrize("shape", [(6, 32, 48, 72), (5, 128, 12, 18), (7, 256, 6, 9), (3, 16, 10, 7), (6, 128, 1, 2),
-                                   (2, 8, 1, 1)])
+                                   (2, 8, 1, 1), (4, 64, 24, 36), (3, 8, 20, 6)])
 def test_fused_se_stats_equals_separate_launches(ops, shape):
     """cm_se_spatial_stats == cm_se_excite_fwd + cm_spatial_stats bit for bit; spatial_apply at every vector width."""
     n, c, h, w = shape
@@ -281,6 +281,10 @@ def test_fused_se_stats_equals_separate_launches(ops, shape):
     out1, z1, s1, fmap1, gate1 = ops.se_spatial_gate_fwd(a2, pooled, w1, w2, w7)
     for a, b in ((z0, z1), (s0, s1), (fmap0, fmap1), (gate0, gate1), (out0, out1)):
         assert torch.equal(a, b)
+    if h % 2 == 0 and w % 2 == 0:     # fused MaxPool2d(2) of the gated output == separate pooling launch
+        res = ops.se_spatial_gate_fwd(a2, pooled, w1, w2, w7, pool_out=True)
+        assert torch.equal(res[0], out0) and torch.equal(res[5], ops.maxpool2_fwd(out0))
+        assert torch.equal(res[5], F.max_pool2d(out0, 2))
     # against torch
     u = a2 * s0[:, :, None, None]
     m = torch.cat([u.mean(1, keepdim=True), u.amax(1, keepdim=True)], 1)
@@ -490,3 +494,9 @@ def test_conv3x3_split_bf16x6(ops, case):
     F.conv2d(xd, wt.double(), padding=1).backward(dy.double())
     dx = ops.conv3x3_split(dev(dy), wpd, c0 + c1, config=0)
     assert rel_l2(dx, xd.grad) < 2e-6
+    # K split over blockIdx.z (zeroed output + atomics), incl. more splits than k-steps
+    for cfg in (0, 5, 16):
+        for ks in (2, 3, 50):
+            y = ops.conv3x3_split(dev(x0), wps, cout, x1=None if x1 is None else dev(x1), bias=dev(b), resid=dev(r),
+                                  config=cfg + (ks << 8))
+            assert rel_l2(y, ref) < 2e-6, f"config {cfg} ksplit {ks}: {rel_l2(y, ref)}"

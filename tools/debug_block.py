@@ -62,7 +62,7 @@ check(lib.cm_gate_bwd_reduce(D(dout).data_ptr(), A2.data_ptr(), S.data_ptr(), GT
 dmap2 = torch.empty(n, 2, h, w, device="cuda"); dw7 = torch.zeros(98, device="cuda")
 check(lib.cm_conv7_bwd(dgpre.data_ptr(), FM.data_ptr(), D(W7).data_ptr(), dmap2.data_ptr(), dw7.data_ptr(), torch.empty(int(lib.cm_conv7_bwd_scratch_elems(n, h)), device='cuda').data_ptr(), n, h, w, st))
 ds = torch.empty(n, co, device="cuda")
-check(lib.cm_se_bwd_reduce(D(dout).data_ptr(), A2.data_ptr(), S.data_ptr(), GT.data_ptr(), dmap2.data_ptr(), FM.data_ptr(), cnt2.data_ptr(), ds.data_ptr(), n, co, hw, st))
+check(lib.cm_se_bwd_reduce(D(dout).data_ptr(), A2.data_ptr(), S.data_ptr(), GT.data_ptr(), dmap2.data_ptr(), FM.data_ptr(), cnt2.data_ptr(), ds.data_ptr(), n, co, hw, None, 0, None, st))
 print("ds %.2e  cnt max %d  dgpre %.1e" % (rel(ds, s.grad.flatten(1)), int(cnt2.max().item()), rel(dgpre, (fmap.grad * 0 + 0).sum(1) if False else dgpre)))
 dsr = s.grad.flatten(1)
 print("per (n,c) rel:", [f"{((ds[i//co, i%co].item()-dsr[i//co,i%co].item())/abs(dsr[i//co,i%co].item())):.1e}" for i in range(min(n*co, 32))])
