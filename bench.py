@@ -218,6 +218,9 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
         }
         print(json.dumps(out))
+        if os.environ.get("CM_TUNE_CACHE"):       # lets a profiled re-run skip the autotuner's trial launches
+            from climate_amd import ops as _ops
+            _ops.save_tuned(os.environ["CM_TUNE_CACHE"])
     if world > 1:
         dist.destroy_process_group()
 

@@ -521,6 +521,9 @@ int cm_se_excite_fwd(const float* pooled, const float* w1, const float* w2, floa
   return 0;
 }
 
+/* (A single-launch variant whose weight-gradient workgroups recompute dsig / dz instead of waiting for them was
+ * measured 2x SLOWER under graph replay -- 164 vs 75 us over the seven blocks: its serial per-sample dots are latency
+ * bound -- so the two-launch form stays.  tools/se_bwd_bench.py times this entry point.) */
 int cm_se_excite_bwd(const float* ds, const float* s, const float* z, const float* pooled, const float* w1,
                      const float* w2, float* dsig, float* dz, float* dpool, float* dw1, float* dw2, int n, int c,
                      int cr, cm_stream stream) {

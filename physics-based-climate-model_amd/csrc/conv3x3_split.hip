@@ -35,6 +35,7 @@ struct SplitArgs {
   float* out;
   long long sto;
   int N, H, W, Cout, CoutP, nsteps, tiles_x, tiles_y;   // nsteps = 16-channel k-steps (= LDS stages)
+  int dbg;     // diagnostic ablation bits (CM_CONVS_DBG): 1 skip global loads, 2 skip MFMA phase, 8 skip convert+store
   int ksplit;  // > 1: blockIdx.z owns a share of the k-steps and accumulates into a pre-zeroed output with atomics
 };
 
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_split_kernel(SplitArgs a) 
       second = true;
     }
     cvalid_pending = cvalid;
+    if (a.dbg & 1) return;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int e = tid + i * THREADS;
@@ -132,6 +134,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_split_kernel(SplitArgs a) 
     }
   };
   auto store_chunk = [&]() {
+    if (a.dbg & 8) return;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int e = tid + i * THREADS;
@@ -193,6 +196,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv3x3_split_kernel(SplitArgs a) 
     store_chunk();
     __syncthreads();
     if (chunk + 1 < c_end) load_chunk(chunk + 1);
+    if (!(a.dbg & 2))
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       bf16x8 bf[3][NPT];
@@ -342,6 +346,15 @@ constexpr SCfg kS[] = {
     {6, 9, 4, 8, 1, 1},    // 17: 4 x 54 px x 32 co, 8 waves
     {12, 18, 1, 8, 1, 1},  // 18: 216 px x 32 co, 8 waves
     {16, 24, 1, 6, 2, 2},  // 19: 384 px x 64 co, 6 waves
+    // Sample groups of 3 and 6: with N = B*T = 192 = 3*64 frames the workgroup count becomes a multiple of the 256 CUs
+    // (S = 4 gives 48 groups -> 0.75 or 1.5 rounds of resident slots: a quarter of the chip idles in the last round).
+    {6, 9, 3, 3, 2, 1},    // 20: 3 x 54 px x 32 co, 3 waves
+    {6, 9, 3, 3, 2, 2},    // 21: 3 x 54 px x 64 co, 3 waves
+    {6, 9, 6, 6, 2, 1},    // 22: 6 x 54 px x 32 co, 6 waves
+    {6, 9, 6, 6, 2, 2},    // 23: 6 x 54 px x 64 co, 6 waves
+    {6, 18, 3, 6, 2, 1},   // 24: 3 x 108 px x 32 co (half images of the 12x18 level), 6 waves
+    {6, 18, 3, 6, 2, 2},   // 25: 3 x 108 px x 64 co
+    {12, 18, 3, 7, 3, 1},  // 26: 3 x 216 px x 32 co, 7 waves
 };
 constexpr int kNumS = sizeof(kS) / sizeof(kS[0]);
 
@@ -393,6 +406,13 @@ int dispatch_s(int cfg, const SplitArgs& a, hipStream_t st) {
     case 17: return launch_s<17, DUAL>(a, st);
     case 18: return launch_s<18, DUAL>(a, st);
     case 19: return launch_s<19, DUAL>(a, st);
+    case 20: return launch_s<20, DUAL>(a, st);
+    case 21: return launch_s<21, DUAL>(a, st);
+    case 22: return launch_s<22, DUAL>(a, st);
+    case 23: return launch_s<23, DUAL>(a, st);
+    case 24: return launch_s<24, DUAL>(a, st);
+    case 25: return launch_s<25, DUAL>(a, st);
+    case 26: return launch_s<26, DUAL>(a, st);
     default: return -22;
   }
 }
@@ -428,6 +448,8 @@ int cm_conv3x3_split(const float* in0, long long st0, int c0, const float* in1, 
   a.N = n; a.H = h; a.W = w; a.Cout = cout;
   a.CoutP = ((cout + 31) / 32) * 32;
   a.nsteps = (c0 + c1 + SKC - 1) / SKC;
+  static const int s_dbg = getenv("CM_CONVS_DBG") ? atoi(getenv("CM_CONVS_DBG")) : 0;
+  a.dbg = s_dbg;
   a.ksplit = config >> 8;                    // bits 8.. = K split over blockIdx.z (0/1 = none)
   config &= 0xff;
   if (a.ksplit > 1 && resid == out) return -22;   // the in-place residual would be zeroed

@@ -51,11 +51,17 @@ USE_SPLIT = os.environ.get("CM_CONV_BF16X6", "1") != "0"
 class _Packs:
     """Both operand forms of the packed 3x3 weights; ``conv(key, ...)`` lets the tuner choose the kernel family."""
 
-    def __init__(self, pk, pks):
+    def __init__(self, pk, pks, uses_fp32=None, packed_fp32=None):
         self.pk, self.pks = pk, pks
+        self.uses_fp32 = uses_fp32 if uses_fp32 is not None else {}
+        self.packed_fp32 = packed_fp32            # keys whose fp32-MFMA operand was re-packed this step (None = all)
 
     def conv(self, key, x0, cout, **kw):
-        return ops.conv3x3(x0, self.pk[key], cout, wps=self.pks.get(key), **kw)
+        wp = self.pk[key] if (self.packed_fp32 is None or key in self.packed_fp32) else None
+        out = ops.conv3x3(x0, wp, cout, wps=self.pks.get(key), **kw)
+        # (-1 = untuned fallback under graph capture, which runs the fp32-MFMA family)
+        self.uses_fp32[key] = self.uses_fp32.get(key, False) or ops.LAST_CONV_CONFIG < ops.SPLIT_BASE
+        return out
 
 
 class Plan:
@@ -86,6 +92,10 @@ class Plan:
         rec.append([0, 0, 0, 0, 0, 0, 0, blk])
         self.pack_table = torch.tensor(rec, dtype=torch.int64).to(dev)
         self.pack_n, self.pack_blocks = len(jobs), blk
+        self._fp32_rec = rec[:-1]
+        self._job_keys = [j[0] for j in jobs]
+        self.uses_fp32: Dict[str, bool] = {}      # per conv key: did any call run the fp32-MFMA family?
+        self._pruned = None                       # (frozenset of keys, table, n, blocks)
         # bf16x6 operand forms of the same weights (the autotuner picks the kernel family per layer)
         self.pks: Dict[str, Tensor] = {}
         if USE_SPLIT:
@@ -130,11 +140,30 @@ class Plan:
     def pack(self):
         from ._lib import check, lib
         st = torch.cuda.current_stream().cuda_stream
-        check(lib.cm_pack_conv3x3_batch(self.pack_table.data_ptr(), self.pack_n, self.pack_blocks, st), "pack_batch")
+        table, n, blocks = self.pack_table, self.pack_n, self.pack_blocks
+        packed = None
+        if self.pks and len(self.uses_fp32) == len(self._job_keys):
+            # every conv has run at least once: pack the fp32-MFMA form only where that family is actually used
+            need = frozenset(k for k in self._job_keys if self.uses_fp32[k])
+            if self._pruned is None or self._pruned[0] != need:
+                if not torch.cuda.is_current_stream_capturing():
+                    rec, blk = [], 0
+                    for k, r in zip(self._job_keys, self._fp32_rec):
+                        if k in need:
+                            nb = max(1, min(512, (self.pk[k].numel() + 1023) // 1024))
+                            rec.append(r[:7] + [blk])
+                            blk += nb
+                    rec.append([0, 0, 0, 0, 0, 0, 0, blk])
+                    self._pruned = (need, torch.tensor(rec, dtype=torch.int64).to(self.pack_table.device), len(rec) - 1,
+                                    blk)
+            if self._pruned is not None and self._pruned[0] == need:
+                packed, table, n, blocks = self._pruned
+        if n > 0:
+            check(lib.cm_pack_conv3x3_batch(table.data_ptr(), n, blocks, st), "pack_batch")
         if self.pks:
             check(lib.cm_pack_conv3x3_split_batch(self.spack_table.data_ptr(), self.pack_n, self.spack_blocks, st),
                   "pack_split_batch")
-        return _Packs(self.pk, self.pks)
+        return _Packs(self.pk, self.pks, self.uses_fp32, packed)
 
     def zero_staging(self):
         _zero_(self.g_arena)

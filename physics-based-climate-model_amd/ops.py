@@ -61,6 +61,30 @@ def tuned_table():
     return dict(_TUNED)
 
 
+def save_tuned(path):
+    """Write the tuned configuration table (call signature -> configuration id) as text, one entry per line."""
+    with open(path, "w") as f:
+        for k, v in sorted(_TUNED.items(), key=repr):
+            f.write(f"{k!r}\t{v}\n")
+
+
+def load_tuned(path):
+    """Pre-load a table written by save_tuned (same GPU model and library build): calls found in it are not re-timed,
+    which keeps autotuner trial launches out of a profiled run."""
+    import ast
+    n = 0
+    with open(path) as f:
+        for line in f:
+            k, v = line.rstrip("\n").split("\t")
+            _TUNED[ast.literal_eval(k)] = int(v)
+            n += 1
+    return n
+
+
+if os.environ.get("CM_TUNE_CACHE") and os.path.exists(os.environ["CM_TUNE_CACHE"]):
+    load_tuned(os.environ["CM_TUNE_CACHE"])
+
+
 def _contig(t):
     if not t.is_contiguous():
         raise RuntimeError("climate_hip ops need contiguous tensors")
@@ -78,6 +102,7 @@ def pack_conv3x3(w, c_off=0, cin=None, dgrad=False):
 
 
 SPLIT_BASE = 1 << 20   # tuned configuration ids >= SPLIT_BASE select the bf16x6 kernel (cm_conv3x3_split)
+LAST_CONV_CONFIG = -1   # configuration the most recent conv3x3() call ran with (the engine prunes unused weight packs)
 
 
 def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1, wps=None):
@@ -106,12 +131,23 @@ def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1, w
         nchunks = (c0 + c1 + 7) // 8
         splits = [1] + [k for k in (2, 4, 8) if nchunks >= 4 * k and not (resid is not None and resid.data_ptr() == out.data_ptr())]
         cands = [c + ((k if k > 1 else 0) << 8) for c in range(lib.cm_conv3x3_num_configs()) for k in splits]
+        if wp is None:              # the caller holds only the bf16x6 operand of this weight
+            cands = []
         use_split = wps is not None and (c1 == 0 or c0 % 16 == 0)
         if use_split:
             ssplits = [1] + [k for k in (2, 4) if (c0 + c1) // 16 >= 4 * k and len(splits) > 1]
             cands += [SPLIT_BASE + c + ((k if k > 1 else 0) << 8) for c in range(lib.cm_conv3x3_split_num_configs())
                       for k in ssplits]
-        config = _pick(("conv3x3", n, h, w, c0, c1, cout, len(splits), use_split), cands, launch, -1)
+        if not cands:
+            raise RuntimeError("conv3x3: no operand form usable for this call")
+        # (same cache key with or without the fp32 operand: a caller that dropped it did so because the cached
+        #  choice for its calls is a bf16x6 configuration)
+        key = ("conv3x3", n, h, w, c0, c1, cout, len(splits), use_split)
+        config = _pick(key, cands, launch, -1 if wp is not None else SPLIT_BASE)
+        if wp is None and config < SPLIT_BASE:      # cached while the fp32 operand still existed: tune bf16x6 only
+            config = _pick(key + ("bf16x6",), cands, launch, SPLIT_BASE)
+    global LAST_CONV_CONFIG
+    LAST_CONV_CONFIG = config
     if config >= SPLIT_BASE:
         check(lib.cm_conv3x3_split(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(wps), _p(bias), _p(resid),
                                    0 if resid is None else resid.stride(0), _p(out), out.stride(0), n, h, w, cout,

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round-end measurement batch on the GPU box (run through gpurun from the repo root):
+#   bash tools/measure_round.sh r01
+# Writes everything under gpurun_out/<tag>/; copy what should be judged into profiles/<tag>/.
+#   1. pytest -m gpu log          2. bench.py JSON line (with the CPU baseline leg)
+#   3. rocprofv3 --kernel-trace --stats of the same bench command (kernel_stats CSV)
+#   4. two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counters only, no trace domains) -> pmc_traffic.json
+set -o pipefail
+tag=${1:-r01}
+out=gpurun_out/$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+python -m pytest tests -q -m gpu > $out/pytest_gpu.log 2>&1; tail -2 $out/pytest_gpu.log
+export CM_TUNE_CACHE=$out/tuned.txt   # written by the first run; the profiled runs load it and do no tuning launches
+python bench.py --steps 30 --warmup 5 > $out/bench.json 2> $out/bench.err || { tail -5 $out/bench.err; exit 1; }
+python tools/show_bench.py $out/bench.json | head -8
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --profile-steps 0 > $out/stats.log 2>&1
+f=$(ls $out/stats/*/*kernel_stats.csv 2>/dev/null | tail -1); [ -n "$f" ] && cp $f $out/rocprofv3_kernel_stats.csv
+t=$(ls $out/stats/*/*kernel_trace.csv 2>/dev/null | tail -1); [ -n "$t" ] && python tools/trace_summary.py $t --one-step > $out/one_step_trace.txt
+rm -rf $out/stats
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 0 --no-graph > $out/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 0 --no-graph > $out/pmc_write.log 2>&1
+python tools/pmc_traffic.py $out/pmc_fetch $out/pmc_write $out/pmc_traffic.json | head -8
+rm -rf $out/pmc_fetch $out/pmc_write
+ls -la $out
