@@ -169,6 +169,12 @@ int cm_mse_loss(const float* pred, const float* y, float* loss, float* dpred, lo
 /* dw [oc,c], db [oc] ACCUMULATED */
 int cm_head_bwd(const float* dpred, const float* x, long long sx, const float* w, float* dx, long long sdx, float* dw,
                 float* db, int n, int c, int oc, int hw, cm_stream stream);
+/* cm_head_fwd + cm_mse_loss + cm_head_bwd in one pass over x (the fused training step): loss [1] is ACCUMULATED
+ * (caller zeroes it), dw/db accumulated, dx written; pred_out nullable.  Same per-pixel arithmetic as the three
+ * separate launchers. */
+int cm_head_mse_bwd(const float* x, long long sx, const float* w, const float* b, const float* y, float* pred_out,
+                    float* loss, float* dx, long long sdx, float* dw, float* db, int n, int c, int oc, int hw,
+                    cm_stream stream);
 
 /* ---- optimizer --------------------------------------------------------------------------------------------- *
  * optim.Adam: main_final.py:742-746 (torch defaults).  Flat, 16-byte aligned buffers.  grad_scale multiplies g.  */

@@ -463,9 +463,9 @@ __global__ __launch_bounds__(256) void conv7_fold_kernel(const float* __restrict
   conv7_fold(partials, nrows, rpb, dw7);
 }
 
-// ds[n,c] = sum_p dU * a2, with dU = dout*gate + dmapA/C + dmapM*[U==max]/cnt.  One wave per (n,c), VEC pixels per lane
-// and load.
-template <int VEC>
+// ds[n,c] = sum_p dU * a2, with dU = dout*gate + dmapA/C + dmapM*[U==max]/cnt.  One wave per (n, CG channels), VEC
+// pixels per lane and load; the five per-pixel maps are loaded once for the CG channels.
+template <int VEC, int CG>
 __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const float* __restrict__ dout,
                                                              const float* __restrict__ a2,
                                                              const float* __restrict__ s,
@@ -480,10 +480,9 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const float* __restr
   // side duty of the first workgroups: fold the preceding cm_conv7_bwd's per-workgroup dW7 partials (saves a launch)
   if (c7_partials && blockIdx.x * c7_rpb < c7_rows) conv7_fold(c7_partials, c7_rows, c7_rpb, dw7);
   const int lane = threadIdx.x & 63;
-  const int nc = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nc = (blockIdx.x * 4 + (threadIdx.x >> 6)) * CG;     // first of this wave's CG channels (C % CG == 0)
   if (nc >= NC) return;
   const int n = nc / C;
-  const float sc = s[nc];
   const float inv_c = 1.f / (float)C;
   const vec_t* gp = reinterpret_cast<const vec_t*>(gate + (long long)n * HW);
   const vec_t* da = reinterpret_cast<const vec_t*>(dmap + (long long)n * 2 * HW);
@@ -492,21 +491,32 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const float* __restr
   const vec_t* ct = reinterpret_cast<const vec_t*>(cnt + (long long)n * HW);
   const vec_t* dop = reinterpret_cast<const vec_t*>(dout + (long long)nc * HW);
   const vec_t* ap = reinterpret_cast<const vec_t*>(a2 + (long long)nc * HW);
-  float acc = 0.f;
+  float sc[CG], acc[CG];
+#pragma unroll
+  for (int j = 0; j < CG; ++j) {
+    sc[j] = s[nc + j];
+    acc[j] = 0.f;
+  }
   const int nv = HW / VEC;
   for (int p = lane; p < nv; p += 64) {
-    const vec_t a = ap[p], d = dop[p], g = gp[p], va = da[p], vm = dm[p], m = mx[p], k = ct[p];
+    const vec_t g = gp[p], va = da[p], vm = dm[p], m = mx[p], k = ct[p];
 #pragma unroll
-    for (int q = 0; q < VEC; ++q) {
-      const float av = a[q], dv = d[q], gv = g[q], vav = va[q], vmv = vm[q], mv = m[q], kv = k[q];
-      const float u = av * sc;
-      float dU = dv * gv + vav * inv_c;
-      if (u == mv) dU += vmv / kv;
-      acc += dU * av;
+    for (int j = 0; j < CG; ++j) {
+      const vec_t a = ap[(long long)j * nv + p], d = dop[(long long)j * nv + p];
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) {
+        const float u = a[q] * sc[j];
+        float dU = d[q] * g[q] + va[q] * inv_c;
+        if (u == m[q]) dU += vm[q] / k[q];
+        acc[j] += dU * a[q];
+      }
     }
   }
-  acc = wave_sum(acc);
-  if (lane == 0) ds[nc] = acc;
+#pragma unroll
+  for (int j = 0; j < CG; ++j) {
+    const float t = wave_sum(acc[j]);
+    if (lane == 0) ds[nc + j] = t;
+  }
 }
 
 }  // namespace
@@ -631,7 +641,8 @@ int cm_se_bwd_reduce(const float* dout, const float* a2, const float* s, const f
                      const float* map, const float* cnt, float* ds, int n, int c, int hw, const float* c7_partials,
                      int c7_rows, float* dw7, cm_stream stream) {
   if (n <= 0 || c <= 0 || hw <= 0 || (c7_partials && (c7_rows <= 0 || !dw7))) return -22;
-  const unsigned grid = (unsigned)cdiv((long long)n * c, 4);
+  const int cg = (c % 4 == 0 && (long long)n * c >= 4096) ? 4 : 1;   // channels per wave (needs enough waves)
+  const unsigned grid = (unsigned)cdiv((long long)n * c / cg, 4);
   int fb = 1, rpb = 0;
   if (c7_partials) {
     conv7_fold_split(c7_rows, &fb, &rpb);
@@ -639,9 +650,17 @@ int cm_se_bwd_reduce(const float* dout, const float* a2, const float* s, const f
   }
   const bool al = (((uintptr_t)dout | (uintptr_t)a2 | (uintptr_t)gate | (uintptr_t)dmap | (uintptr_t)map |
                     (uintptr_t)cnt) & 15) == 0;
-#define CM_SEBR(V)                                                                                                  \
-  se_bwd_reduce_kernel<V><<<grid, 256, 0, (hipStream_t)stream>>>(dout, a2, s, gate, dmap, map, cnt, ds, n * c, c, hw, \
-                                                                 c7_partials, c7_rows, rpb, dw7)
+#define CM_SEBR(V)                                                                                               \
+  do {                                                                                                           \
+    if (cg == 4)                                                                                                 \
+      se_bwd_reduce_kernel<V, 4><<<grid, 256, 0, (hipStream_t)stream>>>(dout, a2, s, gate, dmap, map, cnt, ds,   \
+                                                                        n * c, c, hw, c7_partials, c7_rows, rpb, \
+                                                                        dw7);                                    \
+    else                                                                                                         \
+      se_bwd_reduce_kernel<V, 1><<<grid, 256, 0, (hipStream_t)stream>>>(dout, a2, s, gate, dmap, map, cnt, ds,   \
+                                                                        n * c, c, hw, c7_partials, c7_rows, rpb, \
+                                                                        dw7);                                    \
+  } while (0)
   if (al && hw % 4 == 0) CM_SEBR(4);
   else if (al && hw % 2 == 0) CM_SEBR(2);
   else CM_SEBR(1);

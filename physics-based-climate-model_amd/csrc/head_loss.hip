@@ -130,6 +130,113 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   for (int i = tid; i < OC; i += 256) unsafeAtomicAdd(db + i, sh[OC * C + i]);
 }
 
+// Output head, MSE loss and the head's backward in ONE pass over the last decoder activation (fused training step
+// only): per pixel pred = b + W x (same summation order as head_fwd_kernel), d = pred - y, loss += d^2 / total,
+// dpred = 2 d / total, then dx / dW / db exactly as head_bwd_kernel.  x is read from HBM once (the second, chunked
+// walk over the channels hits the cache) and pred / dpred never exist in memory unless `pred_out` asks for them.
+template <int OCT>
+__global__ __launch_bounds__(256) void head_mse_bwd_kernel(const float* __restrict__ x, long long sx,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            const float* __restrict__ y, float* __restrict__ pred_out,
+                                                            float* __restrict__ loss, float* __restrict__ dx,
+                                                            long long sdx, float* __restrict__ dw,
+                                                            float* __restrict__ db, int C, int OC, int HW, int ppb,
+                                                            float inv_total) {
+  extern __shared__ float sh[];  // [OC*C] dW partial + [OC] db partial + [OC*C] weights + [OC] bias
+  __shared__ float red[32];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int n = blockIdx.y;
+  const int p_begin = blockIdx.x * ppb, p_end = min(HW, p_begin + ppb);
+  float* wsh = sh + OC * C + OC;
+  float* bsh = wsh + OC * C;
+  for (int i = tid; i < OC * C + OC; i += 256) sh[i] = 0.f;
+  for (int i = tid; i < OC * C; i += 256) wsh[i] = w[i];
+  for (int i = tid; i < OC; i += 256) bsh[i] = b[i];
+  __syncthreads();
+  float dbp[OCT], lsum = 0.f;
+#pragma unroll
+  for (int o = 0; o < OCT; ++o) dbp[o] = 0.f;
+  // NOTE: one pixel per thread per pass of the outer loop; the dW partials of a 16-channel chunk live in registers
+  // across the thread's pixels, so the chunk loop is outermost and pred is recomputed per chunk only when a thread
+  // owns more than one pixel (ppb <= 256 in practice: exactly one pixel per thread).
+  for (int c0 = 0; c0 < C; c0 += HB_CC) {
+    float dwp[OCT][HB_CC];
+#pragma unroll
+    for (int o = 0; o < OCT; ++o)
+#pragma unroll
+      for (int j = 0; j < HB_CC; ++j) dwp[o][j] = 0.f;
+    for (int p = p_begin + tid; p < p_end; p += 256) {
+      const float* xp = x + (long long)n * sx + p;
+      float acc[OCT];
+#pragma unroll
+      for (int o = 0; o < OCT; ++o) acc[o] = (o < OC) ? bsh[o] : 0.f;
+      for (int c = 0; c < C; ++c) {
+        const float xv = xp[(long long)c * HW];
+#pragma unroll
+        for (int o = 0; o < OCT; ++o)
+          if (o < OC) acc[o] += wsh[o * C + c] * xv;
+      }
+      float dp[OCT];
+#pragma unroll
+      for (int o = 0; o < OCT; ++o) {
+        float d = 0.f;
+        if (o < OC) {
+          d = acc[o] - y[((long long)n * OC + o) * HW + p];
+          if (c0 == 0) {
+            lsum += d * d;
+            if (pred_out) pred_out[((long long)n * OC + o) * HW + p] = acc[o];
+          }
+        }
+        dp[o] = 2.f * d * inv_total;
+      }
+      if (c0 == 0) {
+#pragma unroll
+        for (int o = 0; o < OCT; ++o) dbp[o] += dp[o];
+      }
+#pragma unroll
+      for (int j = 0; j < HB_CC; ++j) {
+        const int c = c0 + j;
+        if (c < C) {
+          const float xv = xp[(long long)c * HW];
+          float g = 0.f;
+#pragma unroll
+          for (int o = 0; o < OCT; ++o) {
+            if (o < OC) {
+              g += wsh[o * C + c] * dp[o];
+              dwp[o][j] += dp[o] * xv;
+            }
+          }
+          dx[(long long)n * sdx + (long long)c * HW + p] = g;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < OCT; ++o) {
+      if (o < OC) {
+#pragma unroll
+        for (int j = 0; j < HB_CC; ++j) {
+          if (c0 + j < C) {
+            const float sred = wave_sum(dwp[o][j]);
+            if (lane == 0) atomicAdd(&sh[o * C + c0 + j], sred);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < OCT; ++o) {
+    if (o < OC) {
+      const float sred = wave_sum(dbp[o]);
+      if (lane == 0) atomicAdd(&sh[OC * C + o], sred);
+    }
+  }
+  lsum = block_sum(lsum, red);
+  __syncthreads();
+  for (int i = tid; i < OC * C; i += 256) unsafeAtomicAdd(dw + i, sh[i]);
+  for (int i = tid; i < OC; i += 256) unsafeAtomicAdd(db + i, sh[OC * C + i]);
+  if (tid == 0) unsafeAtomicAdd(loss, lsum * inv_total);
+}
+
 }  // namespace
 
 extern "C" {
@@ -167,6 +274,25 @@ int cm_head_bwd(const float* dpred, const float* x, long long sx, const float* w
     head_bwd_kernel<4><<<grid, 256, lds, (hipStream_t)stream>>>(dpred, x, sx, w, dx, sdx, dw, db, c, oc, hw, ppb);
   else
     head_bwd_kernel<MAXOC><<<grid, 256, lds, (hipStream_t)stream>>>(dpred, x, sx, w, dx, sdx, dw, db, c, oc, hw, ppb);
+  CM_CHECK_LAUNCH();
+  return 0;
+}
+
+int cm_head_mse_bwd(const float* x, long long sx, const float* w, const float* b, const float* y, float* pred_out,
+                    float* loss, float* dx, long long sdx, float* dw, float* db, int n, int c, int oc, int hw,
+                    cm_stream stream) {
+  if (n <= 0 || c <= 0 || oc <= 0 || oc > MAXOC || hw <= 0) return -22;
+  const int ppb = 256;                                   // one pixel per thread: pred is computed once per pixel
+  const dim3 grid(cdiv(hw, ppb), n);
+  const size_t lds = (size_t)(2 * oc * c + 2 * oc) * sizeof(float);
+  const float inv_total = 1.f / ((float)n * (float)oc * (float)hw);
+#define CM_HMB(T)                                                                                                  \
+  head_mse_bwd_kernel<T><<<grid, 256, lds, (hipStream_t)stream>>>(x, sx, w, b, y, pred_out, loss, dx, sdx, dw, db, \
+                                                                  c, oc, hw, ppb, inv_total)
+  if (oc <= 2) CM_HMB(2);
+  else if (oc <= 4) CM_HMB(4);
+  else CM_HMB(MAXOC);
+#undef CM_HMB
   CM_CHECK_LAUNCH();
   return 0;
 }

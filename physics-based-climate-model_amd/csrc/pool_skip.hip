@@ -77,6 +77,23 @@ __global__ void time_mean_kernel(const float* __restrict__ x, float* __restrict_
   }
 }
 
+// same, 4 elements per thread (chw % 4 == 0, 16-byte aligned bases): one 16-byte load per frame
+__global__ void time_mean_vec4_kernel(const float4* __restrict__ x, float4* __restrict__ y, int B, int T,
+                                      unsigned chw4) {
+  const unsigned total = (unsigned)B * chw4;
+  const float inv = 1.f / (float)T;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned b = i / chw4, r = i - b * chw4;
+    const float4* p = x + (size_t)b * T * chw4 + r;
+    float4 a = p[0];
+    for (int t = 1; t < T; ++t) {
+      const float4 v = p[(size_t)t * chw4];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    y[i] = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+  }
+}
+
 // per-channel sum over samples and pixels: out[c] += sum_{n,p} x[n, c, p]   (bias gradients)
 // (n, p) is walked as one flat index so that small images still fill the workgroup.
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, long long st,
@@ -122,7 +139,14 @@ int cm_maxpool2_bwd(const float* x, const float* dy, const float* dskip, long lo
 
 int cm_time_mean(const float* x, float* y, int b, int t, long long chw, cm_stream stream) {
   if (b <= 0 || t <= 0 || chw <= 0) return -22;
-  time_mean_kernel<<<grid_for((long long)b * chw, 256), 256, 0, (hipStream_t)stream>>>(x, y, b, t, chw);
+  if (chw % 4 == 0 && (long long)b * t * chw < (1ll << 33) && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+    const long long total4 = (long long)b * (chw / 4);
+    const long long blocks = (total4 + 255) / 256;
+    time_mean_vec4_kernel<<<(unsigned)(blocks > 8192 ? 8192 : blocks), 256, 0, (hipStream_t)stream>>>(
+        (const float4*)x, (float4*)y, b, t, (unsigned)(chw / 4));
+  } else {
+    time_mean_kernel<<<grid_for((long long)b * chw, 256), 256, 0, (hipStream_t)stream>>>(x, y, b, t, chw);
+  }
   CM_CHECK_LAUNCH();
   return 0;
 }

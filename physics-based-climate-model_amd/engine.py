@@ -298,8 +298,11 @@ class Saved:
     __slots__ = ("B", "T", "enc", "pools_in", "s4", "gx", "hprev", "call", "bott", "ups", "up_in", "d1", "x_shape")
 
 
-def forward(p: Params, pk, x_seq: Tensor, save: bool = True):
-    """x_seq [B,T,C,H,W] (contiguous, fp32, GPU) -> pred [B,out_ch,H,W], Saved."""
+def forward(p: Params, pk, x_seq: Tensor, save: bool = True, head: bool = True):
+    """x_seq [B,T,C,H,W] (contiguous, fp32, GPU) -> pred [B,out_ch,H,W], Saved.
+
+    ``head=False`` stops before the 1x1 output head (pred is None; ``Saved.d1`` holds its input): the fused training
+    step runs head + loss + head backward as one launch (ops.head_mse_bwd) and passes the result to ``backward``."""
     if x_seq.dim() != 5:
         raise RuntimeError("expected x_seq of shape [B, T, C, H, W]")
     B, T, C, H, W = x_seq.shape
@@ -339,7 +342,7 @@ def forward(p: Params, pk, x_seq: Tensor, save: bool = True):
     d2, cu2 = _block_fwd(p, pk, "up2.conv.", u2, k2, save)
     u1 = ops.convT2x2_fwd(d2, p["up1.up.weight"], p["up1.up.bias"])
     d1, cu1 = _block_fwd(p, pk, "up1.conv.", u1, k1, save)
-    pred = ops.head_fwd(d1, p["head.weight"], p["head.bias"])
+    pred = ops.head_fwd(d1, p["head.weight"], p["head.bias"]) if head else None
 
     if save:
         sv.B, sv.T, sv.x_shape = B, T, tuple(x_seq.shape)
@@ -351,20 +354,25 @@ def forward(p: Params, pk, x_seq: Tensor, save: bool = True):
     return pred, sv
 
 
-def backward(p: Params, pk, g: Params, sv: Saved, dpred: Tensor, need_dx: bool = False):
+def backward(p: Params, pk, g: Params, sv: Saved, dpred: Optional[Tensor], need_dx: bool = False,
+             dd1: Optional[Tensor] = None):
     """Accumulates every parameter gradient into ``g`` (same keys as ``p``; the caller zeroes them) and returns
-    d(x_seq) when ``need_dx``.  ``post_conv.*`` is untouched (never used by the forward, as in the reference)."""
+    d(x_seq) when ``need_dx``.  ``post_conv.*`` is untouched (never used by the forward, as in the reference).
+    Either ``dpred`` (gradient w.r.t. the prediction) or ``dd1`` (gradient w.r.t. the head's input, with the head's
+    own parameter gradients already accumulated by ops.head_mse_bwd) is given."""
     plan = get_plan(p, g, need_dx)
     gw = plan.gw
     plan.zero_staging()
-    ss = _SideStream(dpred.device, OVERLAP_WGRAD)
+    dev = (dpred if dpred is not None else dd1).device
+    ss = _SideStream(dev, OVERLAP_WGRAD)
     B, T = sv.B, sv.T
     c1, c2, c3, c4 = sv.enc
     cu3, cu2, cu1 = sv.ups
     bott, d3, d2 = sv.up_in
 
     # ---- head + decoder --------------------------------------------------------------------------------
-    dd1 = ops.head_bwd(dpred, sv.d1, p["head.weight"], g["head.weight"], g["head.bias"])
+    if dd1 is None:
+        dd1 = ops.head_bwd(dpred, sv.d1, p["head.weight"], g["head.weight"], g["head.bias"])
     dcat1 = _block_bwd(p, pk, g, gw, ss, "up1.conv.", cu1, dd1)
     b1 = cu1.x0.shape[1]
     dd2 = ops.convT2x2_bwd(d2, p["up1.up.weight"], dcat1[:, :b1], g["up1.up.weight"], g["up1.up.bias"])
@@ -380,7 +388,7 @@ def backward(p: Params, pk, g: Params, sv: Saved, dpred: Tensor, need_dx: bool =
     ch = hprev.shape[2]
     cx = sv.s4.shape[1]
     h8, w8 = hprev.shape[3], hprev.shape[4]
-    dc = torch.empty(B, ch, h8, w8, device=dpred.device, dtype=torch.float32)
+    dc = torch.empty(B, ch, h8, w8, device=dev, dtype=torch.float32)
     dhrec = None
     for t in range(T - 1, -1, -1):
         ops.lstm_gates_bwd(gx[:, t], call[:, t - 1] if t > 0 else None, call[:, t], dbott if t == T - 1 else None,

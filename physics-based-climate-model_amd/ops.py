@@ -419,6 +419,16 @@ def head_bwd(dpred, x, w, dw, db):
     return dx
 
 
+def head_mse_bwd(x, w, b, y, loss, dw, db, pred_out=None):
+    """Head + MSE + head backward in one launch (fused step): loss[0] += mse, dw/db += grads; returns d(x)."""
+    n, c, h, wd = x.shape
+    oc = w.shape[0]
+    dx = torch.empty(n, c, h, wd, device=x.device, dtype=torch.float32)
+    check(lib.cm_head_mse_bwd(_p(x), x.stride(0), _p(_contig(w)), _p(b), _p(_contig(y)), _p(pred_out), _p(loss), _p(dx),
+                              dx.stride(0), _p(dw), _p(db), n, c, oc, h * wd, _stream()), "head_mse_bwd")
+    return dx
+
+
 def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):
     check(lib.cm_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
                            grad_scale, _stream()), "adam")

@@ -24,11 +24,13 @@ class HotPathTrainer:
         self.device = dev
         self.flat = model._flat if model._flat is not None else model.flatten_parameters_()
         self.nt = model.n_flat_trainable
-        self.grad = torch.zeros(self.nt, device=dev, dtype=torch.float32)
+        # flat gradient with the loss scalar behind it: one zero-fill launch clears both
+        self._gradbuf = torch.zeros(self.nt + 1, device=dev, dtype=torch.float32)
+        self.grad = self._gradbuf[:self.nt]
         self.m = torch.zeros(self.nt, device=dev, dtype=torch.float32)
         self.v = torch.zeros(self.nt, device=dev, dtype=torch.float32)
         self.adam_state = torch.zeros(4, device=dev, dtype=torch.float32)   # device-side step counter + corrections
-        self.loss = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.loss = self._gradbuf[self.nt:]
         self.world = ddp.world_size() if distributed is None else (ddp.world_size() if distributed else 1)
         if self.world > 1:
             ddp.broadcast_parameters(self.flat)
@@ -41,12 +43,13 @@ class HotPathTrainer:
     def _fwd_bwd(self, x, y):
         p = self.model._param_dict()
         g = self.model._views(self.grad)
-        check(lib.cm_zero(self.grad.data_ptr(), self.nt * 4, torch.cuda.current_stream().cuda_stream), "zero")
+        check(lib.cm_zero(self._gradbuf.data_ptr(), (self.nt + 1) * 4, torch.cuda.current_stream().cuda_stream),
+              "zero")
         pk = engine.get_plan(p, None, False).pack()
-        pred, sv = engine.forward(p, pk, x, save=True)
-        check(lib.cm_mse_loss(pred.data_ptr(), y.data_ptr(), self.loss.data_ptr(), pred.data_ptr(), pred.numel(),
-                              torch.cuda.current_stream().cuda_stream), "mse")       # dpred overwrites pred in place
-        engine.backward(p, pk, g, sv, pred, need_dx=False)
+        _, sv = engine.forward(p, pk, x, save=True, head=False)
+        # output head + MSE + the head's backward: one pass over the last decoder activation
+        dd1 = ops.head_mse_bwd(sv.d1, p["head.weight"], p["head.bias"], y, self.loss, g["head.weight"], g["head.bias"])
+        engine.backward(p, pk, g, sv, None, need_dx=False, dd1=dd1)
 
     def _adam(self):
         b1, b2 = self.betas
@@ -75,18 +78,35 @@ class HotPathTrainer:
         if key not in self._graphs:
             self._capture(key, x, y)
         sx, sy = self._static[key]
-        sx.copy_(x, non_blocking=True)
-        sy.copy_(y, non_blocking=True)
+        if x.data_ptr() != sx.data_ptr():          # a loader may write straight into input_buffers() and skip this copy
+            sx.copy_(x, non_blocking=True)
+        if y.data_ptr() != sy.data_ptr():
+            sy.copy_(y, non_blocking=True)
         g1, g2 = self._graphs[key]
         g1.replay()
-        if self.world > 1:
+        if g2 is not None:                         # distributed: gradient exchange between the two graphs
             ddp.allreduce_gradients(self.grad)
-        g2.replay()
+            g2.replay()
         return self.loss
 
+    def input_buffers(self, x_shape, y_shape):
+        """The static device buffers the replayed graph reads for this batch shape (allocated on first use).  A data
+        loader that copies each batch straight into them (H2D or D2D) and passes them to ``step`` saves the per-step
+        device-to-device copy of the batch."""
+        key = (tuple(x_shape), tuple(y_shape))
+        if key not in self._static:
+            self._static[key] = (torch.zeros(*x_shape, device=self.device, dtype=torch.float32),
+                                 torch.zeros(*y_shape, device=self.device, dtype=torch.float32))
+        return self._static[key]
+
     def _capture(self, key, x, y):
-        """Record {fwd, loss, bwd} and {Adam} as two hipGraphs; the RCCL all-reduce runs between them."""
-        sx, sy = x.clone(), y.clone()
+        """Record {fwd, loss, bwd} and {Adam} as two hipGraphs with the RCCL all-reduce between them, or -- on one
+        GPU -- the whole step as a single graph."""
+        sx, sy = self.input_buffers(x.shape, y.shape)
+        if x.data_ptr() != sx.data_ptr():
+            sx.copy_(x)
+        if y.data_ptr() != sy.data_ptr():
+            sy.copy_(y)
         # warm-up on a side stream (lazy module loading, allocator pools) WITHOUT touching the optimizer state
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -95,10 +115,13 @@ class HotPathTrainer:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g1 = torch.cuda.CUDAGraph()
+        g2 = None
         with torch.cuda.graph(g1):
             self._fwd_bwd(sx, sy)
-        g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g2):
-            self._adam()
+            if self.world == 1:
+                self._adam()
+        if self.world > 1:
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2):
+                self._adam()
         self._graphs[key] = (g1, g2)
-        self._static[key] = (sx, sy)

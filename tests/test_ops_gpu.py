@@ -360,6 +360,8 @@ def test_time_mean(ops):
     x = rnd(b * t, 4, 6, 10, seed=31)
     y = ops.time_mean(dev(x), b, t)
     assert rel_l2(y, x.reshape(b, t, 4, 6, 10).mean(1)) < 1e-6
+    x = rnd(2 * 3, 3, 5, 7, seed=31)                       # chw % 4 != 0: scalar path
+    assert rel_l2(ops.time_mean(dev(x), 2, 3), x.reshape(2, 3, 3, 5, 7).mean(1)) < 1e-6
 
 
 @pytest.mark.parametrize("shape", [(2, 32, 16, 6, 9), (3, 20, 12, 12, 18), (1, 64, 32, 24, 36)])
@@ -407,6 +409,26 @@ def test_head_and_mse(ops):
     dw = torch.zeros_like(dev(wt)); db = torch.zeros_like(dev(b))
     dx = ops.head_bwd(dpred, dev(x), dev(wt), dw, db)
     assert rel_l2(dx, xd.grad) < TOL and rel_l2(dw, wd.grad) < TOL and rel_l2(db, bd.grad) < TOL
+
+
+@pytest.mark.parametrize("shape", [(3, 32, 2, 48, 72), (2, 8, 3, 5, 7), (1, 20, 1, 16, 24)])
+def test_head_mse_bwd_equals_separate_launches(ops, shape):
+    """cm_head_mse_bwd == cm_head_fwd + cm_mse_loss + cm_head_bwd (same per-pixel arithmetic, one pass over x)."""
+    n, c, oc, h, w = shape
+    x = dev(rnd(n, c, h, w, seed=50)); wt = dev(rnd(oc, c, 1, 1, seed=51, scale=c ** -0.5)); b = dev(rnd(oc, seed=52))
+    y = dev(rnd(n, oc, h, w, seed=53))
+    pred = ops.head_fwd(x, wt, b)
+    loss0, dpred = ops.mse_loss(pred, y)
+    dw0 = torch.zeros_like(wt); db0 = torch.zeros_like(b)
+    dx0 = ops.head_bwd(dpred, x, wt, dw0, db0)
+    loss1 = torch.zeros(1, device="cuda"); dw1 = torch.zeros_like(wt); db1 = torch.zeros_like(b)
+    pred1 = torch.empty_like(pred)
+    dx1 = ops.head_mse_bwd(x, wt, b, y, loss1, dw1, db1, pred_out=pred1)
+    assert torch.equal(pred1, pred) and torch.equal(dx1, dx0)
+    assert abs(loss1.item() - loss0.item()) < 1e-6 * abs(loss0.item())
+    assert rel_l2(dw1, dw0) < 1e-6 and rel_l2(db1, db0) < 1e-6
+    ref = F.mse_loss(F.conv2d(x, wt, b), y)
+    assert abs(loss1.item() - ref.item()) < 1e-5 * ref.item()
 
 
 def test_adam_matches_torch(ops):
