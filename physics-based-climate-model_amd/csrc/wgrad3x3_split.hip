@@ -331,6 +331,11 @@ __global__ __launch_bounds__(192 * KS) void wgrad3x3_split_kernel(WsArgs a) {
     }
 }
 
+// (A producer / consumer form -- three MFMA-only kernel-row waves fed by two dedicated staging waves through a four-slot
+// ring -- was built and measured in round 1: correct, but 15-20 % SLOWER (256->256 @6x9: 112 vs 93 us).  Its ablation
+// showed why: the staging side alone takes 105 us on two waves; the fp32 -> 3 x bf16 conversion is VALU work of the
+// same order as the MFMA time and needs all four SIMDs, so concentrating it on dedicated waves starves it.)
+
 struct WsCfg {
   int tw, mo, ks;
 };
@@ -347,13 +352,15 @@ template <int I, bool DUAL>
 int launch_ws(WsArgs a, int rounds4, hipStream_t st) {
   constexpr WsCfg c = kWs[I];
   using G = WsGeom<c.tw, c.mo, c.ks>;
+  constexpr size_t LDSB = G::LDS;
+  constexpr int NTHR = 192 * c.ks;
   auto kern = wgrad3x3_split_kernel<c.tw, c.mo, c.ks, DUAL>;
   static int occ = 0;
   if (occ == 0) {
     int nb = 0;
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSB) != hipSuccess)
       return -22;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 192 * c.ks, G::LDS) != hipSuccess || nb < 1) nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, NTHR, LDSB) != hipSuccess || nb < 1) nb = 1;
     occ = nb;
   }
   const int tiles_ci = cdiv(a.C0 + a.C1, 32), tiles_co = cdiv(a.Cout, 32 * c.mo);
@@ -373,7 +380,7 @@ int launch_ws(WsArgs a, int rounds4, hipStream_t st) {
   int z = (int)(target < a.nunits ? target : a.nunits);
   if (z >= 8) z = z / 8 * 8;                  // whole XCD rounds
   z = cdiv(a.nunits, cdiv(a.nunits, z));      // equal unit counts per workgroup (up to one)
-  kern<<<dim3(z, tiles_ci, tiles_co), 192 * c.ks, G::LDS, st>>>(a);
+  kern<<<dim3(z, tiles_ci, tiles_co), NTHR, LDSB, st>>>(a);
   CM_CHECK_LAUNCH();
   return 0;
 }

@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--T", type=int, default=6)
     ap.add_argument("--what", default="both")
     ap.add_argument("--split", action="store_true", help="also time the bf16x6 kernel on the forward shapes")
+    ap.add_argument("--all", action="store_true", help="print every configuration's time, not only the best six")
     ap.add_argument("--only", default="", help="comma-separated layer names (default: all)")
     ap.add_argument("--skip-fp32", action="store_true", help="with --split: time only the bf16x6 kernels")
     args = ap.parse_args()
@@ -120,7 +121,7 @@ def main():
                 tot.setdefault("wgrad_split", 0.0)
                 tot["wgrad_split"] += res[0][0]
                 print(f"wgs   {name:8s} N={n:3d} {ci:3d}->{co:3d} @{h}x{w}: best cfg {res[0][1]:>5s} {res[0][0]:7.1f} us "
-                      f"{flops / res[0][0] / 1e6:6.1f} TF | " + " ".join(f"{c}:{t:.0f}" for t, c in res[1:6]))
+                      f"{flops / res[0][0] / 1e6:6.1f} TF | " + " ".join(f"{c}:{t:.0f}" for t, c in res[1:(99 if args.all else 6)]))
     print("sum of best (us):", {k: round(v, 1) for k, v in tot.items()}, "(lstm.h counted once; it runs T-1 times)")
 
 
