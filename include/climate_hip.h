@@ -93,6 +93,11 @@ int cm_gn_silu_bwd(const float* x, const float* gamma, const float* beta, const 
                    long long st_dA, float* dx, float* dgamma, float* dbeta, int n, int c, int hw, int groups,
                    cm_stream stream);
 /* same, with the gradient wrt y rebuilt on the fly from the SE / spatial-gate backward maps (see below). */
+/* y = SiLU(GroupNorm(x)) from the stored statistics of cm_gn_silu_fwd.  cm_gn_silu_bwd_gated recomputes the forward
+ * activation this way instead of reading `a2` back (its `a2` argument is unused and may be NULL); the result is
+ * bit-identical to what cm_gn_silu_fwd wrote, which the amax tie test depends on. */
+int cm_gn_silu_apply(const float* x, const float* gamma, const float* beta, const float* stats, float* y, int n, int c,
+                     int hw, int groups, cm_stream stream);
 int cm_gn_silu_bwd_gated(const float* x, const float* gamma, const float* beta, const float* stats,
                          const float* a2, const float* dout, const float* gate, const float* dmap, const float* fmap,
                          const float* cnt, const float* s, const float* dpool, float* dx, float* dgamma,

@@ -27,6 +27,24 @@ __device__ __forceinline__ float group_sum(float v) {
 // sigmoid with the hardware exp / rcp (v_exp_f32, v_rcp_f32): ~1e-7 relative, far inside the 1e-4 parity budget
 __device__ __forceinline__ float fast_sigmoid(float u) { return __frcp_rn(1.f + __expf(-u)); }
 
+// The forward value a = SiLU(GroupNorm(v)) with every rounding pinned (explicit round-to-nearest intrinsics, no
+// contraction freedom): the gated backward RECOMPUTES it from the pre-norm input instead of reading the stored
+// activation back (one of its four large streams), and the amax tie test `a*s == max_c(a*s)` needs the recomputed
+// value to be bit-identical to what the forward stored.  tests: test_gn_recompute_is_bit_exact.
+__device__ __forceinline__ void gn_affine(float gamma, float beta, float mean, float rstd, float& ga, float& be) {
+  ga = __fmul_rn(gamma, rstd);
+  be = __fsub_rn(beta, __fmul_rn(__fmul_rn(mean, rstd), gamma));
+}
+__device__ __forceinline__ float gn_silu_parts(float v, float ga, float be, float& u, float& sg) {
+  u = __fmaf_rn(v, ga, be);
+  sg = __frcp_rn(__fadd_rn(1.f, __expf(-u)));
+  return __fmul_rn(u, sg);
+}
+__device__ __forceinline__ float gn_silu_value(float v, float ga, float be) {
+  float u, sg;
+  return gn_silu_parts(v, ga, be, u, sg);
+}
+
 template <bool VEC, int LPC>   // LPC lanes cooperate on one channel (64: a wave, 16: four channels per wave)
 __global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_kernel(const float* __restrict__ x,
                                                                    const float* __restrict__ gamma,
@@ -76,7 +94,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_kernel(const float* __
   const int lane = tid % LPC, wave = tid / LPC;
   for (int cl = wave; cl < cpg; cl += GN_THREADS / LPC) {
     const int c = g * cpg + cl;
-    const float ga = gamma[c] * rstd, be = beta[c] - mean * rstd * gamma[c];
+    float ga, be;
+    gn_affine(gamma[c], beta[c], mean, rstd, ga, be);
     const float* xc = xg + (long long)cl * HW;
     float* yc = yg + (long long)cl * HW;
     float ps = 0.f;
@@ -86,18 +105,16 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_kernel(const float* __
       for (int i = lane; i < HW / 4; i += LPC) {
         const float4 v = x4[i];
         float4 o;
-        float u;
-        u = v.x * ga + be; o.x = u * fast_sigmoid(u);
-        u = v.y * ga + be; o.y = u * fast_sigmoid(u);
-        u = v.z * ga + be; o.z = u * fast_sigmoid(u);
-        u = v.w * ga + be; o.w = u * fast_sigmoid(u);
+        o.x = gn_silu_value(v.x, ga, be);
+        o.y = gn_silu_value(v.y, ga, be);
+        o.z = gn_silu_value(v.z, ga, be);
+        o.w = gn_silu_value(v.w, ga, be);
         y4[i] = o;
         ps += (o.x + o.y) + (o.z + o.w);
       }
     } else {
       for (int i = lane; i < HW; i += LPC) {
-        const float u = xc[i] * ga + be;
-        const float o = u * fast_sigmoid(u);
+        const float o = gn_silu_value(xc[i], ga, be);
         yc[i] = o;
         ps += o;
       }
@@ -110,8 +127,24 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_kernel(const float* __
 }
 
 // Extra inputs of the gated variant (all per ConvBlock, see attention_gates.hip for their producers).
+// y = SiLU(GroupNorm(x)) from STORED statistics (mean, rstd per (sample, group)): the recomputation the gated backward
+// performs inline, exposed so that its bit-exactness against the forward kernels' output can be tested.
+__global__ void gn_silu_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, const float* __restrict__ stats,
+                                     float* __restrict__ y, int C, int HW, int G, long long total) {
+  const int cpg = C / G;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long nc = i / HW;
+    const int c = (int)(nc % C);
+    const long long ng = (nc / C) * G + c / cpg;
+    float ga, be;
+    gn_affine(gamma[c], beta[c], stats[2 * ng], stats[2 * ng + 1], ga, be);
+    y[i] = gn_silu_value(x[i], ga, be);
+  }
+}
+
 struct GateBwd {
-  const float* a2;     // [N,C,HW]  stored forward activation (bit-exact operand of the max/tie test)
+  const float* a2;     // [N,C,HW]  stored forward activation -- NOT read: recomputed bit-exactly (gn_silu_value)
   const float* dout;   // [N,C,HW]  gradient wrt the ConvBlock output
   const float* gate;   // [N,HW]    spatial gate (post-sigmoid)
   const float* dmap;   // [N,2,HW]  gradient wrt [mean_c U, max_c U]
@@ -153,7 +186,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_kernel(const float* __
     const vec_t* xc = reinterpret_cast<const vec_t*>(x + nc * HW);
     vec_t* dxc = reinterpret_cast<vec_t*>(dx + nc * HW);
     const vec_t* dAc = MODE == 0 ? reinterpret_cast<const vec_t*>(dA + (long long)n * st_dA + (long long)c * HW) : nullptr;
-    const vec_t* a2c = MODE == 1 ? reinterpret_cast<const vec_t*>(gb.a2 + nc * HW) : nullptr;
+    float gaf = 0.f, bef = 0.f;               // forward affine of this channel (recomputation of a2)
+    if (MODE == 1) gn_affine(ga, be, mean, rstd, gaf, bef);
     const vec_t* doc = MODE == 1 ? reinterpret_cast<const vec_t*>(gb.dout + nc * HW) : nullptr;
     const vec_t* gtc = MODE == 1 ? reinterpret_cast<const vec_t*>(gb.gate + (long long)n * HW) : nullptr;
     const vec_t* dac = MODE == 1 ? reinterpret_cast<const vec_t*>(gb.dmap + (long long)n * 2 * HW) : nullptr;
@@ -165,25 +199,34 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_kernel(const float* __
     float sd = 0.f, sdx = 0.f;
     for (int i = lane; i < HWV; i += LPC) {
       const vec_t xv = xc[i];
-      vec_t up;
+      vec_t up, ufv, sgv;
       if (MODE == 0) {
         up = dAc[i];
       } else {
-        const vec_t a2v = a2c[i], dov = doc[i], gtv = gtc[i], dav = dac[i], dmv = dmc[i], mxv = mxc[i], ctv = ctc[i];
+        const vec_t dov = doc[i], gtv = gtc[i], dav = dac[i], dmv = dmc[i], mxv = mxc[i], ctv = ctc[i];
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-          const float U = a2v[k] * sc;                  // bit-exact forward product: operand of the tie test
+          float uf, sgf;
+          const float U = gn_silu_parts(xv[k], gaf, bef, uf, sgf) * sc;   // bit-exact forward product: tie test operand
           float dU = dov[k] * gtv[k] + dav[k] * inv_c;
           if (U == mxv[k]) dU += dmv[k] / ctv[k];
           up[k] = dU * sc + dpl;
+          ufv[k] = uf;
+          sgv[k] = sgf;
         }
       }
       vec_t duv;
 #pragma unroll
       for (int k = 0; k < V; ++k) {
         const float xh = (xv[k] - mean) * rstd;
-        const float u = xh * ga + be;
-        const float sg = fast_sigmoid(u);
+        float u, sg;
+        if (MODE == 1) {           // reuse the forward pre-activation and its sigmoid (one exp per element)
+          u = ufv[k];
+          sg = sgv[k];
+        } else {
+          u = xh * ga + be;
+          sg = fast_sigmoid(u);
+        }
         const float du = up[k] * (sg * (1.f + u * (1.f - sg)));
         duv[k] = du;
         sd += du;
@@ -273,13 +316,13 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_reg_kernel(const float
     const int cl = r / RPC, i = (r % RPC) * 64 + lane;
     const bool ok = r < rows && i < HWV;
     const int c = g * cpg + (r < rows ? cl : 0);
-    const float ga = gamma[c] * rstd, be = beta[c] - mean * rstd * gamma[c];
+    float ga, be;
+    gn_affine(gamma[c], beta[c], mean, rstd, ga, be);
     float4 o;
-    float u;
-    u = v[q].x * ga + be; o.x = u * fast_sigmoid(u);
-    u = v[q].y * ga + be; o.y = u * fast_sigmoid(u);
-    u = v[q].z * ga + be; o.z = u * fast_sigmoid(u);
-    u = v[q].w * ga + be; o.w = u * fast_sigmoid(u);
+    o.x = gn_silu_value(v[q].x, ga, be);
+    o.y = gn_silu_value(v[q].y, ga, be);
+    o.z = gn_silu_value(v[q].z, ga, be);
+    o.w = gn_silu_value(v[q].w, ga, be);
     if (ok) yg[(long long)cl * HWV + i] = o;
     if (pooled) {
       float ps = ok ? (o.x + o.y) + (o.z + o.w) : 0.f;
@@ -323,12 +366,16 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_reg_kernel(const float
     const long long e = nc * HWV + (ok ? i : 0);               // quad index inside [N,C,HW]
     const float ga = gamma[c], be = beta[c];
     const float4 xv = reinterpret_cast<const float4*>(x)[e];
-    float4 up;
+    float4 up, uf = make_float4(0.f, 0.f, 0.f, 0.f), sf = uf;
     if (MODE == 0) {
       up = reinterpret_cast<const float4*>(dA + (long long)n * st_dA + (long long)c * HW)[ok ? i : 0];
     } else {
       const long long m0 = (long long)n * HWV + (ok ? i : 0);
-      const float4 a2v = reinterpret_cast<const float4*>(gb.a2)[e], dov = reinterpret_cast<const float4*>(gb.dout)[e];
+      const float4 dov = reinterpret_cast<const float4*>(gb.dout)[e];
+      float gaf, bef;                                  // forward affine of this channel (recomputation of a2)
+      gn_affine(ga, be, mean, rstd, gaf, bef);
+      const float4 a2v = make_float4(gn_silu_parts(xv.x, gaf, bef, uf.x, sf.x), gn_silu_parts(xv.y, gaf, bef, uf.y, sf.y),
+                                     gn_silu_parts(xv.z, gaf, bef, uf.z, sf.z), gn_silu_parts(xv.w, gaf, bef, uf.w, sf.w));
       const float4 gtv = reinterpret_cast<const float4*>(gb.gate)[m0], ctv = reinterpret_cast<const float4*>(gb.cnt)[m0];
       const float4 dav = reinterpret_cast<const float4*>(gb.dmap)[2 * (long long)n * HWV + (ok ? i : 0)];
       const float4 dmv = reinterpret_cast<const float4*>(gb.dmap)[(2 * (long long)n + 1) * HWV + (ok ? i : 0)];
@@ -346,17 +393,23 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_reg_kernel(const float
       up.w = one(a2v.w, dov.w, gtv.w, dav.w, dmv.w, mxv.w, ctv.w);
     }
     float sd = 0.f, sdx = 0.f;
-    auto elem = [&](float xe, float upe, float& xho, float& duo) {
+    auto elem = [&](float xe, float upe, float ufe, float sfe, float& xho, float& duo) {
       const float h = (xe - mean) * rstd;
-      const float u = h * ga + be;
-      const float sg = fast_sigmoid(u);
+      float u, sg;
+      if (MODE == 1) {             // reuse the forward pre-activation and its sigmoid (one exp per element)
+        u = ufe;
+        sg = sfe;
+      } else {
+        u = h * ga + be;
+        sg = fast_sigmoid(u);
+      }
       const float d = ok ? upe * (sg * (1.f + u * (1.f - sg))) : 0.f;
       xho = h; duo = d; sd += d; sdx += d * h;
     };
-    elem(xv.x, up.x, xh[q].x, du[q].x);
-    elem(xv.y, up.y, xh[q].y, du[q].y);
-    elem(xv.z, up.z, xh[q].z, du[q].z);
-    elem(xv.w, up.w, xh[q].w, du[q].w);
+    elem(xv.x, up.x, uf.x, sf.x, xh[q].x, du[q].x);
+    elem(xv.y, up.y, uf.y, sf.y, xh[q].y, du[q].y);
+    elem(xv.z, up.z, uf.z, sf.z, xh[q].z, du[q].z);
+    elem(xv.w, up.w, uf.w, sf.w, xh[q].w, du[q].w);
     sd = wave_sum(sd);
     sdx = wave_sum(sdx);
     if (lane == 0 && r < rows) {
@@ -455,6 +508,17 @@ int cm_gn_silu_bwd(const float* x, const float* gamma, const float* beta, const 
   if (vec) { if (narrow) GN_BWD(4, 16); else GN_BWD(4, 64); }
   else     { if (narrow) GN_BWD(1, 16); else GN_BWD(1, 64); }
 #undef GN_BWD
+  CM_CHECK_LAUNCH();
+  return 0;
+}
+
+int cm_gn_silu_apply(const float* x, const float* gamma, const float* beta, const float* stats, float* y, int n, int c,
+                     int hw, int groups, cm_stream stream) {
+  if (n <= 0 || c <= 0 || hw <= 0 || groups <= 0 || c % groups) return -22;
+  const long long total = (long long)n * c * hw;
+  const long long blocks = (total + 255) / 256;
+  gn_silu_apply_kernel<<<(int)(blocks > 4096 ? 4096 : blocks), 256, 0, (hipStream_t)stream>>>(x, gamma, beta, stats, y, c,
+                                                                                              hw, groups, total);
   CM_CHECK_LAUNCH();
   return 0;
 }

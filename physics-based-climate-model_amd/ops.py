@@ -241,6 +241,15 @@ def gn_silu_fwd(x, gamma, beta, want_pooled=False):
     return y, stats, pooled
 
 
+def gn_silu_apply(x, gamma, beta, stats):
+    """SiLU(GroupNorm(x)) from stored statistics (bit-identical to gn_silu_fwd's output)."""
+    n, c, h, w = x.shape
+    y = torch.empty_like(_contig(x))
+    check(lib.cm_gn_silu_apply(_p(x), _p(gamma), _p(beta), _p(stats), _p(y), n, c, h * w, GN_GROUPS, _stream()),
+          "gn_silu_apply")
+    return y
+
+
 def gn_silu_bwd(x, gamma, beta, stats, dA, dgamma, dbeta):
     n, c, h, w = x.shape
     dx = torch.empty_like(_contig(x))

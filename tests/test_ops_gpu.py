@@ -215,6 +215,19 @@ def _gates_roundtrip(ops, a2, w1, w2, w7, dout, gamma=None, beta=None, y2=None):
     return out, (s, fmap, gate, dmap, cnt, dpool), dw1, dw2, dw7
 
 
+@pytest.mark.parametrize("shape", [(3, 16, 6, 9), (2, 32, 16, 24), (2, 8, 12, 18), (1, 64, 48, 72), (4, 256, 6, 9),
+                                   (2, 128, 12, 18), (3, 8, 5, 7), (6, 32, 48, 72)])
+def test_gn_recompute_is_bit_exact(ops, shape):
+    """The gated backward recomputes a2 = SiLU(GN(y2)) instead of reading it: must equal the forward's output bit
+    for bit in every forward kernel variant (vector / scalar, 64 / 16 lanes per channel), or amax ties are missed."""
+    n, c, h, w = shape
+    x = dev(rnd(n, c, h, w, seed=61)) * 3.0 + 0.5
+    gamma = dev(rnd(c, seed=62)) + 1.0
+    beta = dev(rnd(c, seed=63))
+    y, stats, _ = ops.gn_silu_fwd(x, gamma, beta, want_pooled=True)
+    assert torch.equal(ops.gn_silu_apply(x, gamma, beta, stats), y)
+
+
 def test_se_and_spatial_gate_golden(ops):
     """SE and SpatialGate fixtures from the reference (incl. amax ties): forward through the HIP kernels."""
     g = load_golden("se_block.npz")
