@@ -79,6 +79,13 @@ int cm_wgrad3x3_split_num_configs(void);
 int cm_wgrad3x3_split(const float* x0, long long sx0, int c0, const float* x1, long long sx1, int c1, const float* dy,
                       long long sdy, float* g, int ctot, int c_off, int n, int h, int w, int cout, int config,
                       cm_stream stream);
+/* Weight gradient for VERY FEW input channels (cin * 9 <= 64, the first layer: src/unet.py:36 at
+ * src/unet_convlstm_attention.py:35): GEMM columns are the (input channel, tap) pairs, fp32 MFMA, same staging
+ * format G[cout][9][ctot].  w % 4 == 0, w <= 320, st_dy % 4 == 0.  scratch: cm_wgrad3x3_smallc_scratch_elems()
+ * floats of workspace (per-workgroup partial tiles, folded by a second launch inside the call). */
+long long cm_wgrad3x3_smallc_scratch_elems(int n, int h, int w, int cout);
+int cm_wgrad3x3_smallc(const float* x, long long sx, int cin, const float* dy, long long sdy, float* g, int ctot,
+                       int c_off, int n, int h, int w, int cout, float* scratch, cm_stream stream);
 int cm_wgrad3x3_unpack(const float* g, float* dw, int cout, int ctot, float scale, cm_stream stream);
 /* batched form: records of 8 int64 {g ptr, dw ptr, cout, ctot, 0, 0, 0, first block}, as cm_pack_conv3x3_batch */
 int cm_wgrad3x3_unpack_batch(const void* descs_dev, int ndesc, int total_blocks, float scale, cm_stream stream);

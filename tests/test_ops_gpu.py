@@ -171,6 +171,24 @@ def test_wgrad3x3_split_all_configs(ops, case):
             assert dw[:, :4].abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("case", [(6, 5, 32, 48, 72), (3, 7, 40, 10, 12), (2, 1, 8, 6, 8), (5, 5, 64, 24, 36),
+                                  (2, 3, 32, 3, 320)])
+def test_wgrad3x3_smallc(ops, case):
+    """First-layer weight gradient (cin * 9 <= 64 columns = (channel, tap) pairs) vs float64 autograd."""
+    n, cin, cout, h, w = case
+    x = rnd(n, cin, h, w, seed=71)
+    dy = rnd(n, cout, h, w, seed=72)
+    wt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wt, padding=1).backward(dy.double())
+    ctot = cin + 3
+    g = torch.zeros(cout, 9, ctot, device="cuda")
+    for _ in range(2):                                   # accumulates, scratch needs no initialisation
+        ops.wgrad3x3(dev(x), dev(dy), g, c_off=3, config=ops.SMALLC_CFG)
+    dw = ops.wgrad3x3_unpack(g)
+    assert rel_l2(dw[:, 3:] / 2.0, wt.grad) < TOL
+    assert dw[:, :3].abs().max().item() == 0.0
+
+
 def test_wgrad3x3_split_strided_samples(ops):
     """Time-slice views ([B,T,...] buffers, sample stride T*C*H*W) feed the bf16x6 weight gradient without copies."""
     b, t, c, cout, h, w = 10, 3, 32, 32, 6, 9

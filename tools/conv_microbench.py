@@ -111,6 +111,10 @@ def main():
             tot["wgrad"] += res[0][0] if res[0][1] != "-" else 0.0
             print(f"wgrad {name:8s} N={n:3d} {ci:3d}->{co:3d} @{h}x{w}: best cfg {res[0][1]:>5s} {res[0][0]:7.1f} us "
                   f"{flops / res[0][0] / 1e6:6.1f} TF | " + " ".join(f"{c}:{t:.0f}" for t, c in res[1:5]))
+            if x1 is None and ci * 9 <= 64 and w % 4 == 0:
+                t = timeit(lambda: ops.wgrad3x3(x0, dy, g, config=ops.SMALLC_CFG))
+                print(f"wgsc  {name:8s} N={n:3d} {ci:3d}->{co:3d} @{h}x{w}: {t:7.1f} us {flops / t / 1e6:6.1f} TF "
+                      f"(cm_wgrad3x3_smallc, two launches)")
             if args.split and (x1 is None or x0.shape[1] % 32 == 0):
                 res = []
                 for cfg in range(lib.cm_wgrad3x3_split_num_configs()):
