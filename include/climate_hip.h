@@ -60,6 +60,12 @@ int cm_conv3x3_split(const float* in0, long long st0, int c0, const float* in1, 
                      const void* wps, const float* bias, const float* resid, long long st_resid, float* out,
                      long long st_out, int n, int h, int w, int cout, int config, cm_stream stream);
 
+/* Forward conv for VERY FEW input channels (cin * 9 <= 64; the first layer, src/unet.py:36 at
+ * src/unet_convlstm_attention.py:35): the reduction index is the (input channel, tap) pair, fp32 MFMA, weights read
+ * UNPACKED ([cout][cin][3][3]).  out = conv(x, w) + bias.  w_ <= 320. */
+int cm_conv3x3_smallc(const float* x, long long sx, int cin, const float* w, const float* bias, float* out,
+                      long long st_out, int n, int h, int w_, int cout, cm_stream stream);
+
 /* ---- conv3x3 weight gradient ------------------------------------------------------------------------------- *
  * convolution_backward (weight) of the convs above.  Accumulates (fp32 atomics) into a tap-major staging buffer
  * g[cout][9][ctot] that the caller zeroes once per step; cm_wgrad3x3_unpack transposes it to [cout][ctot][3][3].

@@ -51,14 +51,15 @@ USE_SPLIT = os.environ.get("CM_CONV_BF16X6", "1") != "0"
 class _Packs:
     """Both operand forms of the packed 3x3 weights; ``conv(key, ...)`` lets the tuner choose the kernel family."""
 
-    def __init__(self, pk, pks, uses_fp32=None, packed_fp32=None):
+    def __init__(self, pk, pks, uses_fp32=None, packed_fp32=None, raw=None):
         self.pk, self.pks = pk, pks
+        self.raw = raw or {}                      # key -> unpacked weight (few-input-channels forward kernel)
         self.uses_fp32 = uses_fp32 if uses_fp32 is not None else {}
         self.packed_fp32 = packed_fp32            # keys whose fp32-MFMA operand was re-packed this step (None = all)
 
     def conv(self, key, x0, cout, **kw):
         wp = self.pk[key] if (self.packed_fp32 is None or key in self.packed_fp32) else None
-        out = ops.conv3x3(x0, wp, cout, wps=self.pks.get(key), **kw)
+        out = ops.conv3x3(x0, wp, cout, wps=self.pks.get(key), w_raw=self.raw.get(key), **kw)
         # (-1 = untuned fallback under graph capture, which runs the fp32-MFMA family)
         self.uses_fp32[key] = self.uses_fp32.get(key, False) or ops.LAST_CONV_CONFIG < ops.SPLIT_BASE
         return out
@@ -94,6 +95,9 @@ class Plan:
         self.pack_n, self.pack_blocks = len(jobs), blk
         self._fp32_rec = rec[:-1]
         self._job_keys = [j[0] for j in jobs]
+        # forward convs whose whole reduction (cin * 9) fits one 64-wide MFMA column block also offer the unpacked weight
+        self.raw = {key: p[name] for key, name, off, cin, dg in jobs
+                    if not dg and off == 0 and cin == p[name].shape[1] and cin * 9 <= 64}
         self.uses_fp32: Dict[str, bool] = {}      # per conv key: did any call run the fp32-MFMA family?
         self._pruned = None                       # (frozenset of keys, table, n, blocks)
         # bf16x6 operand forms of the same weights (the autotuner picks the kernel family per layer)
@@ -163,7 +167,7 @@ class Plan:
         if self.pks:
             check(lib.cm_pack_conv3x3_split_batch(self.spack_table.data_ptr(), self.pack_n, self.spack_blocks, st),
                   "pack_split_batch")
-        return _Packs(self.pk, self.pks, self.uses_fp32, packed)
+        return _Packs(self.pk, self.pks, self.uses_fp32, packed, self.raw)
 
     def zero_staging(self):
         _zero_(self.g_arena)

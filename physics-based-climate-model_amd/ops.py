@@ -110,13 +110,16 @@ def pack_conv3x3(w, c_off=0, cin=None, dgrad=False):
 
 
 SPLIT_BASE = 1 << 20   # tuned configuration ids >= SPLIT_BASE select the bf16x6 kernel (cm_conv3x3_split)
+SMALLC_CFG = 1 << 22   # tuned configuration id of the few-input-channels kernels (cm_conv3x3_smallc / cm_wgrad3x3_smallc)
 LAST_CONV_CONFIG = -1   # configuration the most recent conv3x3() call ran with (the engine prunes unused weight packs)
 
 
-def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1, wps=None):
+def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1, wps=None, w_raw=None):
     """out = conv3x3(cat(x0, x1), wp) + bias + resid.  x0/x1: [N,C,H,W] (sample stride may exceed C*H*W).
 
-    ``wp`` is the fp32-MFMA operand (cm_pack_conv3x3); ``wps`` (optional) the bf16x6 operand of the same weight.
+    ``wp`` is the fp32-MFMA operand (cm_pack_conv3x3); ``wps`` (optional) the bf16x6 operand of the same weight;
+    ``w_raw`` (optional) the unpacked [cout, cin, 3, 3] parameter, which adds the few-input-channels kernel
+    (cm_conv3x3_smallc) to the candidates when cin * 9 <= 64.
     With config < 0 the autotuner times both kernel families on this call signature and keeps the faster one."""
     n, c0, h, w = x0.shape
     c1 = 0 if x1 is None else x1.shape[1]
@@ -130,6 +133,9 @@ def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1, w
         def launch(cfg, _scratch=[None]):
             if _scratch[0] is None:
                 _scratch[0] = torch.empty(n, cout, h, w, device=x0.device, dtype=torch.float32)
+            if cfg == SMALLC_CFG:
+                return lib.cm_conv3x3_smallc(_p(x0), x0.stride(0), c0, _p(w_raw), _p(bias), _p(_scratch[0]),
+                                             _scratch[0].stride(0), n, h, w, cout, _stream())
             if cfg >= SPLIT_BASE:
                 return lib.cm_conv3x3_split(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(wps), _p(bias), None, 0,
                                             _p(_scratch[0]), _scratch[0].stride(0), n, h, w, cout, cfg - SPLIT_BASE,
@@ -146,16 +152,24 @@ def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1, w
             ssplits = [1] + [k for k in (2, 4) if (c0 + c1) // 16 >= 4 * k and len(splits) > 1]
             cands += [SPLIT_BASE + c + ((k if k > 1 else 0) << 8) for c in range(lib.cm_conv3x3_split_num_configs())
                       for k in ssplits]
+        use_smallc = (w_raw is not None and c1 == 0 and c0 * 9 <= 64 and w <= 320 and resid is None
+                      and tuple(w_raw.shape) == (cout, c0, 3, 3) and w_raw.is_contiguous())
+        if use_smallc:
+            cands.append(SMALLC_CFG)
         if not cands:
             raise RuntimeError("conv3x3: no operand form usable for this call")
         # (same cache key with or without the fp32 operand: a caller that dropped it did so because the cached
         #  choice for its calls is a bf16x6 configuration)
-        key = ("conv3x3", n, h, w, c0, c1, cout, len(splits), use_split)
+        key = ("conv3x3", n, h, w, c0, c1, cout, len(splits), use_split) + (("smallc",) if use_smallc else ())
         config = _pick(key, cands, launch, -1 if wp is not None else SPLIT_BASE)
         if wp is None and config < SPLIT_BASE:      # cached while the fp32 operand still existed: tune bf16x6 only
             config = _pick(key + ("bf16x6",), cands, launch, SPLIT_BASE)
     global LAST_CONV_CONFIG
     LAST_CONV_CONFIG = config
+    if config == SMALLC_CFG:
+        check(lib.cm_conv3x3_smallc(_p(x0), x0.stride(0), c0, _p(w_raw), _p(bias), _p(out), out.stride(0), n, h, w, cout,
+                                    _stream()), "conv3x3_smallc")
+        return out
     if config >= SPLIT_BASE:
         check(lib.cm_conv3x3_split(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(wps), _p(bias), _p(resid),
                                    0 if resid is None else resid.stride(0), _p(out), out.stride(0), n, h, w, cout,
@@ -196,9 +210,6 @@ def conv3x3_split(x0, wps, cout, x1=None, bias=None, resid=None, out=None, confi
 
 
 WGRAD_BF16X6 = os.environ.get("CM_WGRAD_BF16X6", "1") != "0"
-
-
-SMALLC_CFG = 1 << 22    # tuned configuration id of the few-input-channels weight gradient (cm_wgrad3x3_smallc)
 
 
 def _wgrad_call(x0, dy, g, c_off, x1, config):

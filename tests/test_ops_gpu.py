@@ -172,6 +172,21 @@ def test_wgrad3x3_split_all_configs(ops, case):
 
 
 @pytest.mark.parametrize("case", [(6, 5, 32, 48, 72), (3, 7, 40, 10, 12), (2, 1, 8, 6, 8), (5, 5, 64, 24, 36),
+                                  (2, 3, 32, 3, 320), (1, 5, 16, 7, 9)])
+def test_conv3x3_smallc(ops, case):
+    """First-layer forward conv (reduction index = (channel, tap) pair, unpacked weights) vs float64."""
+    n, cin, cout, h, w = case
+    x = rnd(n, cin, h, w, seed=75); wt = rnd(cout, cin, 3, 3, seed=76, scale=(9 * cin) ** -0.5); b = rnd(cout, seed=77)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    y = ops.conv3x3(dev(x), None, cout, bias=dev(b), w_raw=dev(wt), config=ops.SMALLC_CFG)
+    assert rel_l2(y, ref) < 2e-6
+    # through the tuner, next to the packed forms
+    y2 = ops.conv3x3(dev(x), ops.pack_conv3x3(dev(wt)), cout, bias=dev(b), wps=ops.pack_conv3x3_split(dev(wt)),
+                     w_raw=dev(wt))
+    assert rel_l2(y2, ref) < 2e-6
+
+
+@pytest.mark.parametrize("case", [(6, 5, 32, 48, 72), (3, 7, 40, 10, 12), (2, 1, 8, 6, 8), (5, 5, 64, 24, 36),
                                   (2, 3, 32, 3, 320)])
 def test_wgrad3x3_smallc(ops, case):
     """First-layer weight gradient (cin * 9 <= 64 columns = (channel, tap) pairs) vs float64 autograd."""

@@ -74,6 +74,10 @@ def main():
             tot["conv"] += res[0][0]
             print(f"conv  {name:8s} N={n:3d} {ci:3d}->{co:3d} @{h}x{w}: best cfg {res[0][1]:2d} {res[0][0]:7.1f} us "
                   f"{flops / res[0][0] / 1e6:6.1f} TF | " + " ".join(f"{c}:{t:.0f}" for t, c in res[1:6]))
+            if x1 is None and ci * 9 <= 64:
+                t = timeit(lambda: ops.conv3x3(x0, None, co, out=out, w_raw=wt, config=ops.SMALLC_CFG))
+                print(f"convsc {name:8s} N={n:3d} {ci:3d}->{co:3d} @{h}x{w}: {t:7.1f} us {flops / t / 1e6:6.1f} TF "
+                      f"(cm_conv3x3_smallc)")
             if args.split:
                 wps = ops.pack_conv3x3_split(wt)
                 res = []
