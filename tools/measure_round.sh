@@ -13,9 +13,9 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python -m pytest tests -q -m gpu > $out/pytest_gpu.log 2>&1; tail -2 $out/pytest_gpu.log
 export CM_TUNE_CACHE=$out/tuned.txt   # written by the first run; the profiled runs load it and do no tuning launches
 python bench.py --steps 30 --warmup 5 > $out/bench.json 2> $out/bench.err || { tail -5 $out/bench.err; exit 1; }
-python tools/show_bench.py $out/bench.json | head -8
+python tools/show_bench.py $out/bench.json > $out/bench_table.txt; head -8 $out/bench_table.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --profile-steps 0 > $out/stats.log 2>&1
-f=$(ls $out/stats/*/*kernel_stats.csv 2>/dev/null | tail -1); [ -n "$f" ] && cp $f $out/rocprofv3_kernel_stats.csv
+f=$(ls $out/stats/*/*kernel_stats.csv 2>/dev/null | tail -1); [ -n "$f" ] && cp $f $out/rocprofv3_kernel_stats.csv && python tools/stats_by_family.py $out/rocprofv3_kernel_stats.csv > $out/rocprofv3_kernel_stats_by_family.txt
 t=$(ls $out/stats/*/*kernel_trace.csv 2>/dev/null | tail -1); [ -n "$t" ] && python tools/trace_summary.py $t --one-step > $out/one_step_trace.txt
 rm -rf $out/stats
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 0 --no-graph > $out/pmc_fetch.log 2>&1
