@@ -39,8 +39,14 @@ struct SplitArgs {
   int ksplit;  // > 1: blockIdx.z owns a share of the k-steps and accumulates into a pre-zeroed output with atomics
 };
 
+// 4-wave workgroups with one 32x32 tile per wave sit 2 registers above the 3-waves-per-SIMD allocation (170 of 168):
+// ask for three resident workgroups so that the allocator trims them (LDS allows three: <= 53 KB each).
+constexpr int split_min_blocks(int waves, int npt, int wm) {
+  return (npt * wm == 1 && waves == 4) ? 3 : 1;   // -> 12 waves per CU = 3 per SIMD
+}
+
 template <int TH, int TW, int S, int WAVES, int NPT, int WM, bool DUAL>
-__global__ __launch_bounds__(WAVES * 64) void conv3x3_split_kernel(SplitArgs a) {
+__global__ __launch_bounds__(WAVES * 64, split_min_blocks(WAVES, NPT, WM)) void conv3x3_split_kernel(SplitArgs a) {
   constexpr int THREADS = WAVES * 64;
   constexpr int PITCH = TW + 2;
   constexpr int SS = (TH + 2) * PITCH;
@@ -355,6 +361,7 @@ constexpr SCfg kS[] = {
     {6, 18, 3, 6, 2, 1},   // 24: 3 x 108 px x 32 co (half images of the 12x18 level), 6 waves
     {6, 18, 3, 6, 2, 2},   // 25: 3 x 108 px x 64 co
     {12, 18, 3, 7, 3, 1},  // 26: 3 x 216 px x 32 co, 7 waves
+    {6, 18, 1, 4, 1, 1},   // 27: 108 px x 32 co (half images of the 12x18 level), three workgroups per CU
 };
 constexpr int kNumS = sizeof(kS) / sizeof(kS[0]);
 
@@ -413,6 +420,7 @@ int dispatch_s(int cfg, const SplitArgs& a, hipStream_t st) {
     case 24: return launch_s<24, DUAL>(a, st);
     case 25: return launch_s<25, DUAL>(a, st);
     case 26: return launch_s<26, DUAL>(a, st);
+    case 27: return launch_s<27, DUAL>(a, st);
     default: return -22;
   }
 }
