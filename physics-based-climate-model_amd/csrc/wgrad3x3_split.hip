@@ -51,8 +51,12 @@ struct WsGeom {
   static constexpr size_t LDS = (size_t)(STAGE > RED ? STAGE : RED) * 16;
 };
 
+// LEAN form (KS = 2, MO = 1): no conversion in the MFMA shadow and no fragment ping-pong, which brings the kernel under
+// 168 registers so that TWO 6-wave workgroups share a CU (3 waves per SIMD instead of 1.5).
+constexpr bool ws_lean(int mo, int ks) { return mo == 1 && ks == 2; }
+
 template <int TW, int MO, int KS, bool DUAL>
-__global__ __launch_bounds__(192 * KS) void wgrad3x3_split_kernel(WsArgs a) {
+__global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 2 : 1) void wgrad3x3_split_kernel(WsArgs a) {
   using G = WsGeom<TW, MO, KS>;
   constexpr int THREADS = 192 * KS;
   constexpr int NPAIR = G::NPAIR, XP = G::XP, DP = G::DP, BCO = G::BCO, XSLOT = G::XSLOT;
@@ -90,7 +94,8 @@ __global__ __launch_bounds__(192 * KS) void wgrad3x3_split_kernel(WsArgs a) {
   constexpr int NIT = cdiv_c(NI, THREADS);       // items per thread
   constexpr int NUNIT = 16 * NIT;                // conversion units (one split3_pair each) per thread and iteration
   // converting in the MFMA shadow keeps 48 result registers per item alive across the barrier: only where they fit
-  constexpr bool SHADOW = NIT == 1 && MO == 1 && THREADS <= 384;
+  constexpr bool LEAN = ws_lean(MO, KS);
+  constexpr bool SHADOW = NIT == 1 && MO == 1 && THREADS <= 384 && !LEAN;
   bool it_x[NIT];
   int it_ch[NIT], it_c0[NIT], it_rec[NIT];       // channel inside the tile, first column, first LDS record
 #pragma unroll
@@ -224,26 +229,39 @@ __global__ __launch_bounds__(192 * KS) void wgrad3x3_split_kernel(WsArgs a) {
 #pragma unroll
           for (int pc = 0; pc < 3; ++pc) bf[buf][pc] = __builtin_bit_cast(bf16x8, xb[pc * 32 * XP + 2 * j + d - 1]);
         };
+        if (LEAN) {
+#pragma unroll
+          for (int s = 0; s < NSTEP; ++s) {
+            const int jj = s / 3, d = s % 3;
+            if (d == 0) load_a(0, jj);
+            load_b(0, jj, d);
+            if (NPAIR % KS == 0 || jb + jj < NPAIR) {
+#pragma unroll
+              for (int m = 0; m < MO; ++m) acc[m][d] = mfma_bf16x6(af[0][m], bf[0], acc[m][d]);
+            }
+          }
+        } else {
         load_a(0, 0);
-        load_b(0, 0, 0);
-#pragma unroll
-        for (int s = 0; s < NSTEP; ++s) {
-          const int jj = s / 3, d = s % 3;
-          if (s + 1 < NSTEP) {
-            const int nj = (s + 1) / 3, nd = (s + 1) % 3;
-            if (nd == 0) load_a(nj & 1, nj);
-            load_b((s + 1) & 1, nj, nd);
+          load_b(0, 0, 0);
+  #pragma unroll
+          for (int s = 0; s < NSTEP; ++s) {
+            const int jj = s / 3, d = s % 3;
+            if (s + 1 < NSTEP) {
+              const int nj = (s + 1) / 3, nd = (s + 1) % 3;
+              if (nd == 0) load_a(nj & 1, nj);
+              load_b((s + 1) & 1, nj, nd);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the reads of step s+1 ahead of the MFMAs of step s
+            if (KS == 1 || NPAIR % KS == 0 || jb + jj < NPAIR) {
+  #pragma unroll
+              for (int m = 0; m < MO; ++m) acc[m][d] = mfma_bf16x6(af[jj & 1][m], bf[s & 1], acc[m][d]);
+            }
+            if (SHADOW && s >= S0 && !(a.dbg & 8)) {
+  #pragma unroll
+              for (int c = (s - S0) * UPS; c < (s - S0 + 1) * UPS && c < NUNIT; ++c) convert_unit(c);
+            }
+            __builtin_amdgcn_sched_barrier(0);
           }
-          __builtin_amdgcn_sched_barrier(0);   // keep the reads of step s+1 ahead of the MFMAs of step s
-          if (KS == 1 || NPAIR % KS == 0 || jb + jj < NPAIR) {
-#pragma unroll
-            for (int m = 0; m < MO; ++m) acc[m][d] = mfma_bf16x6(af[jj & 1][m], bf[s & 1], acc[m][d]);
-          }
-          if (SHADOW && s >= S0 && !(a.dbg & 8)) {
-#pragma unroll
-            for (int c = (s - S0) * UPS; c < (s - S0 + 1) * UPS && c < NUNIT; ++c) convert_unit(c);
-          }
-          __builtin_amdgcn_sched_barrier(0);
         }
         converted = true;
       }

@@ -32,6 +32,16 @@ def test_cabi_argument_errors_are_reported_not_crashed():
     assert lib.cm_gn_silu_fwd(None, None, None, None, None, None, 2, 12, 64, 8, 1e-5, None) == -22   # 12 % 8 != 0
     assert lib.cm_maxpool2_fwd(None, None, 4, 7, 8, None) == -22                                   # odd height
     assert lib.cm_head_fwd(None, 0, None, None, None, 1, 8, 9, 64, None) == -22                     # out_ch > 8
+    # entry points added for the bf16x6 / first-layer / fused kernels validate before touching the device, too
+    assert lib.cm_conv3x3_split(None, 0, 24, None, 0, 8, None, None, None, 0, None, 0, 2, 8, 8, 8, 0, None) == -22   # c0 % 16
+    assert lib.cm_wgrad3x3_split(None, 0, 24, None, 0, 8, None, 0, None, 32, 0, 2, 8, 8, 8, 0, None) == -22          # c0 % 32
+    assert lib.cm_wgrad3x3_smallc(None, 0, 8, None, 0, None, 8, 0, 2, 8, 8, 8, None, None) == -22                    # cin*9 > 64
+    assert lib.cm_conv3x3_smallc(None, 0, 8, None, None, None, 0, 2, 8, 8, 8, None) == -22                           # cin*9 > 64
+    assert lib.cm_spatial_apply(None, None, None, None, None, None, 1, 2, 4, 7, 8, None) == -22     # pooled output, odd height
+    assert lib.cm_conv7_bwd(None, None, None, None, None, None, 2, 8, 8, None) == -22               # no scratch
+    assert lib.cm_head_mse_bwd(None, 0, None, None, None, None, None, None, 0, None, None, 1, 8, 9, 64, None) == -22
+    assert lib.cm_conv7_bwd_scratch_elems(4, 20) == 4 * 3 * 98
+    assert lib.cm_wgrad3x3_smallc_scratch_elems(2, 8, 8, 40) == 2 * 2 * 32 * 64
 
 
 @pytest.mark.parametrize("base,in_ch", [(8, 5), (16, 7), (32, 5)])
