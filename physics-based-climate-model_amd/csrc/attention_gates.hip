@@ -144,6 +144,7 @@ __global__ __launch_bounds__(256) void spatial_stats_kernel(const float* __restr
 // SE excite + spatial statistics in one launch: every workgroup recomputes its sample's s = sigmoid(W2 relu(W1 p)) into
 // LDS (2*C*Cr MACs, nothing next to its 64 x C pixel reads; bit-identical across workgroups: same order), the first
 // pixel block of each sample also stores z and s for the backward pass.
+template <int VEC>
 __global__ __launch_bounds__(256) void se_spatial_stats_kernel(const float* __restrict__ pooled,
                                                                 const float* __restrict__ w1,
                                                                 const float* __restrict__ w2,
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void se_spatial_stats_kernel(const float* __re
                                                                 float* __restrict__ s, float* __restrict__ map, int C,
                                                                 int Cr, int HW) {
   extern __shared__ float sh[];  // [C] pooled, then s; [Cr] hidden
-  __shared__ float ssum[4][64], smax[4][64];
+  __shared__ float ssum[4][64 * VEC], smax[4][64 * VEC];
   float* p = sh;
   float* hsh = sh + C;
   const int n = blockIdx.y, tid = threadIdx.x;
@@ -176,25 +177,40 @@ __global__ __launch_bounds__(256) void se_spatial_stats_kernel(const float* __re
     if (blockIdx.x == 0) s[(long long)n * C + c] = sv;
   }
   __syncthreads();
-  const int px = blockIdx.x * 64 + lane;
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  const int px = (blockIdx.x * 64 + lane) * VEC;              // HW % VEC == 0 (host)
   const bool live = px < HW;
   const float* ap = a2 + (long long)n * C * HW + (live ? px : 0);
   const int cper = (C + 3) / 4, c0 = slice * cper, c1 = min(C, c0 + cper);
-  float sum = 0.f, mx = -INFINITY;
+  vec_t sum, mx;
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) { sum[q] = 0.f; mx[q] = -INFINITY; }
 #pragma unroll 8
   for (int c = c0; c < c1; ++c) {
-    const float u = ap[(long long)c * HW] * p[c];
-    sum += u;
-    mx = fmaxf(mx, u);
+    const vec_t av = *reinterpret_cast<const vec_t*>(ap + (long long)c * HW);
+    const float sc = p[c];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      const float u = av[q] * sc;
+      sum[q] += u;
+      mx[q] = fmaxf(mx[q], u);
+    }
   }
-  ssum[slice][lane] = sum;
-  smax[slice][lane] = mx;
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) {
+    ssum[slice][lane * VEC + q] = sum[q];
+    smax[slice][lane * VEC + q] = mx[q];
+  }
   __syncthreads();
   if (slice == 0 && live) {
-    const float t = ((ssum[0][lane] + ssum[1][lane]) + ssum[2][lane]) + ssum[3][lane];
-    const float m = fmaxf(fmaxf(smax[0][lane], smax[1][lane]), fmaxf(smax[2][lane], smax[3][lane]));
-    map[((long long)n * 2) * HW + px] = t / (float)C;
-    map[((long long)n * 2 + 1) * HW + px] = m;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      const int l = lane * VEC + q;
+      const float t = ((ssum[0][l] + ssum[1][l]) + ssum[2][l]) + ssum[3][l];
+      const float m = fmaxf(fmaxf(smax[0][l], smax[1][l]), fmaxf(smax[2][l], smax[3][l]));
+      map[((long long)n * 2) * HW + px + q] = t / (float)C;
+      map[((long long)n * 2 + 1) * HW + px + q] = m;
+    }
   }
 }
 
@@ -310,7 +326,8 @@ __global__ __launch_bounds__(256) void spatial_apply_kernel(const float* __restr
 
 // ------------------------------------------------------------------------------------------------ spatial gate bwd
 // per pixel: dgate = sum_c dout*U; dgpre = dgate*gate*(1-gate); cnt = #{c: U == max}
-// Workgroup = 64 pixels x 4 channel slices, combined through LDS.
+// Workgroup = 64*VEC pixels x 4 channel slices, combined through LDS (VEC = 4: 16-byte loads on wide images).
+template <int VEC>
 __global__ __launch_bounds__(256) void gate_bwd_reduce_kernel(const float* __restrict__ dout,
                                                                const float* __restrict__ a2,
                                                                const float* __restrict__ s,
@@ -318,32 +335,47 @@ __global__ __launch_bounds__(256) void gate_bwd_reduce_kernel(const float* __res
                                                                const float* __restrict__ map,
                                                                float* __restrict__ dgpre, float* __restrict__ cnt,
                                                                int C, int HW) {
-  __shared__ float sdg[4][64], scn[4][64];
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  __shared__ float sdg[4][64 * VEC], scn[4][64 * VEC];
   const int n = blockIdx.y;
   const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
-  const int p = blockIdx.x * 64 + lane;
+  const int p = (blockIdx.x * 64 + lane) * VEC;               // HW % VEC == 0 (host)
   const bool live = p < HW;
   const int pp = live ? p : 0;
-  const float mx = map[((long long)n * 2 + 1) * HW + pp];
+  const vec_t mx = *reinterpret_cast<const vec_t*>(map + ((long long)n * 2 + 1) * HW + pp);
   const float* sp = s + (long long)n * C;
   const int cper = (C + 3) / 4, c0 = slice * cper, c1 = min(C, c0 + cper);
-  float dg = 0.f, k = 0.f;
+  vec_t dg, k;
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) { dg[q] = 0.f; k[q] = 0.f; }
 #pragma unroll 8
   for (int c = c0; c < c1; ++c) {
     const long long i = ((long long)n * C + c) * HW + pp;
-    const float u = a2[i] * sp[c];
-    dg += dout[i] * u;
-    k += (u == mx) ? 1.f : 0.f;
+    const vec_t av = *reinterpret_cast<const vec_t*>(a2 + i), dv = *reinterpret_cast<const vec_t*>(dout + i);
+    const float sc = sp[c];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      const float u = av[q] * sc;
+      dg[q] += dv[q] * u;
+      k[q] += (u == mx[q]) ? 1.f : 0.f;
+    }
   }
-  sdg[slice][lane] = dg;
-  scn[slice][lane] = k;
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) {
+    sdg[slice][lane * VEC + q] = dg[q];
+    scn[slice][lane * VEC + q] = k[q];
+  }
   __syncthreads();
   if (slice == 0 && live) {
-    const float t = ((sdg[0][lane] + sdg[1][lane]) + sdg[2][lane]) + sdg[3][lane];
-    const float kk = (scn[0][lane] + scn[1][lane]) + (scn[2][lane] + scn[3][lane]);
-    const float g = gate[(long long)n * HW + p];
-    dgpre[(long long)n * HW + p] = t * g * (1.f - g);
-    cnt[(long long)n * HW + p] = kk;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      const int l = lane * VEC + q;
+      const float t = ((sdg[0][l] + sdg[1][l]) + sdg[2][l]) + sdg[3][l];
+      const float kk = (scn[0][l] + scn[1][l]) + (scn[2][l] + scn[3][l]);
+      const float g = gate[(long long)n * HW + p + q];
+      dgpre[(long long)n * HW + p + q] = t * g * (1.f - g);
+      cnt[(long long)n * HW + p + q] = kk;
+    }
   }
 }
 
@@ -556,8 +588,14 @@ int cm_spatial_stats(const float* a2, const float* s, float* map, int n, int c, 
 int cm_se_spatial_stats(const float* pooled, const float* w1, const float* w2, const float* a2, float* z, float* s,
                         float* map, int n, int c, int cr, int hw, cm_stream stream) {
   if (n <= 0 || c <= 0 || cr <= 0 || hw <= 0) return -22;
-  se_spatial_stats_kernel<<<dim3(cdiv(hw, 64), n), 256, (c + cr) * sizeof(float), (hipStream_t)stream>>>(
-      pooled, w1, w2, a2, z, s, map, c, cr, hw);
+  const size_t lds = (c + cr) * sizeof(float);
+  // wide images: 4 pixels per lane (16-byte loads); the workgroup count must still cover the 256 CUs
+  if (hw % 4 == 0 && ((uintptr_t)a2 & 15) == 0 && (long long)n * (hw / 256) >= 1024)
+    se_spatial_stats_kernel<4><<<dim3(cdiv(hw, 256), n), 256, lds, (hipStream_t)stream>>>(pooled, w1, w2, a2, z, s, map,
+                                                                                           c, cr, hw);
+  else
+    se_spatial_stats_kernel<1><<<dim3(cdiv(hw, 64), n), 256, lds, (hipStream_t)stream>>>(pooled, w1, w2, a2, z, s, map,
+                                                                                          c, cr, hw);
   CM_CHECK_LAUNCH();
   return 0;
 }
@@ -604,8 +642,14 @@ int cm_spatial_apply(const float* a2, const float* s, const float* map, const fl
 int cm_gate_bwd_reduce(const float* dout, const float* a2, const float* s, const float* gate, const float* map,
                        float* dgpre, float* cnt, int n, int c, int hw, cm_stream stream) {
   if (n <= 0 || c <= 0 || hw <= 0) return -22;
-  gate_bwd_reduce_kernel<<<dim3(cdiv(hw, 64), n), 256, 0, (hipStream_t)stream>>>(dout, a2, s, gate, map, dgpre, cnt, c,
-                                                                                  hw);
+  const bool wide = hw % 4 == 0 && (((uintptr_t)dout | (uintptr_t)a2 | (uintptr_t)map) & 15) == 0 &&
+                    (long long)n * (hw / 256) >= 1024;
+  if (wide)
+    gate_bwd_reduce_kernel<4><<<dim3(cdiv(hw, 256), n), 256, 0, (hipStream_t)stream>>>(dout, a2, s, gate, map, dgpre,
+                                                                                        cnt, c, hw);
+  else
+    gate_bwd_reduce_kernel<1><<<dim3(cdiv(hw, 64), n), 256, 0, (hipStream_t)stream>>>(dout, a2, s, gate, map, dgpre,
+                                                                                       cnt, c, hw);
   CM_CHECK_LAUNCH();
   return 0;
 }

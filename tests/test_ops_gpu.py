@@ -311,7 +311,7 @@ def test_conv_block_chain_golden(ops):
 
 
 @pytest.mark.parametrize("shape", [(6, 32, 48, 72), (5, 128, 12, 18), (7, 256, 6, 9), (3, 16, 10, 7), (6, 128, 1, 2),
-                                   (2, 8, 1, 1), (4, 64, 24, 36), (3, 8, 20, 6)])
+                                   (2, 8, 1, 1), (4, 64, 24, 36), (3, 8, 20, 6), (80, 8, 48, 72)])
 def test_fused_se_stats_equals_separate_launches(ops, shape):
     """cm_se_spatial_stats == cm_se_excite_fwd + cm_spatial_stats bit for bit; spatial_apply at every vector width."""
     n, c, h, w = shape
@@ -359,6 +359,28 @@ def test_conv7_bwd_many_workgroups(ops):
     assert rel_l2(dw7 / 3.0, wt.grad.reshape(-1)) < 1e-5
     dm_ref = torch.autograd.grad(F.conv2d(fm, w7, padding=3), fm, dgpre[:, None])[0]
     assert rel_l2(dmap, dm_ref) < 1e-5
+
+
+def test_gates_bwd_wide_images(ops):
+    """Gate backward on enough 48x72 samples to take the 4-pixels-per-lane kernels: dmap / cnt vs autograd."""
+    torch.manual_seed(5)
+    n, c, h, w = 80, 8, 48, 72
+    a2 = torch.randn(n, c, h, w, device="cuda")
+    pooled = a2.mean((2, 3))
+    w1 = torch.randn(1, c, 1, 1, device="cuda") * 0.3
+    w2 = torch.randn(c, 1, 1, 1, device="cuda") * 0.3
+    w7 = torch.randn(1, 2, 7, 7, device="cuda") * 0.1
+    dout = torch.randn(n, c, h, w, device="cuda")
+    out, z, s, fmap, gate = ops.se_spatial_gate_fwd(a2, pooled, w1, w2, w7)
+    dw1 = torch.zeros_like(w1); dw2 = torch.zeros_like(w2); dw7 = torch.zeros_like(w7)
+    dmap, cnt, dpool = ops.gates_bwd(dout, a2, s, z, pooled, gate, fmap, w1, w2, w7, dw1, dw2, dw7)
+    U = a2 * s[:, :, None, None]
+    assert torch.equal(cnt, (U == fmap[:, 1:2]).float().sum(1))
+    dgpre = (dout * U).sum(1) * gate * (1.0 - gate)
+    m = fmap.clone().requires_grad_(True)
+    wt = w7.clone().requires_grad_(True)
+    F.conv2d(m, wt, padding=3).backward(dgpre[:, None])
+    assert rel_l2(dmap, m.grad) < 1e-5 and rel_l2(dw7, wt.grad) < 1e-5
 
 
 def test_gates_ties_backward(ops):
