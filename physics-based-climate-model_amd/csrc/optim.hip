@@ -81,7 +81,7 @@ __global__ void scale_kernel(float* __restrict__ x, long long n, float s) {
 
 extern "C" {
 
-int cm_version(void) { return 1; }
+int cm_version(void) { return 2; }   // 2: bf16x6 + first-layer entry points, scratch/pooled/db parameters
 const char* cm_arch(void) { return "gfx950"; }
 
 int cm_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,

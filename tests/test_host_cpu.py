@@ -19,7 +19,7 @@ def test_cabi_library_exports_every_declared_symbol():
     dll = lib.load()
     for name in protos:
         assert hasattr(dll, name), name
-    assert lib.cm_version() == 1 and lib.cm_arch() == b"gfx950"
+    assert lib.cm_version() == 2 and lib.cm_arch() == b"gfx950"
     # pure host-side helpers work without a GPU
     assert lib.cm_conv3x3_packed_elems(5, 32) == 16 * 9 * 32
     assert 0 <= lib.cm_conv3x3_pick_config(192, 48, 72, 32) < lib.cm_conv3x3_num_configs()
