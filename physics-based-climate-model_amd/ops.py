@@ -27,7 +27,8 @@ def _p(t):
 
 # --------------------------------------------------------------------------------------------------- autotuning
 # Tile configurations are chosen empirically per call signature the first time it is seen outside graph capture
-# (3 timed launches per configuration into scratch outputs); the choice is cached for the life of the process.
+# (3 timed launches per configuration into scratch outputs, then 10 more for the four leaders); the choice is cached
+# for the life of the process and can be saved / pre-loaded (save_tuned / load_tuned, CM_TUNE_CACHE).
 AUTOTUNE = True
 _TUNED = {}
 
