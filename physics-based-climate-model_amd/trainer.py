@@ -111,7 +111,8 @@ class HotPathTrainer:
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            self._fwd_bwd(sx, sy)
+            self._fwd_bwd(sx, sy)          # autotunes every call signature, learns which weight packs are used
+            self._fwd_bwd(sx, sy)          # builds the pruned pack table (cannot be built during capture)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g1 = torch.cuda.CUDAGraph()
