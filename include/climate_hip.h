@@ -52,7 +52,8 @@ int cm_conv3x3(const float* in0, long long st0, int c0, const float* in1, long l
  * MFMAs per 16-deep k-step, fp32 accumulation.  wps comes from cm_pack_conv3x3_split_batch (descriptor records as
  * cm_pack_conv3x3_batch, with the wp field pointing at cm_conv3x3_split_packed_bytes() bytes).  When in1 is given,
  * c0 must be a multiple of 16.  config bits 0-7 in [0, cm_conv3x3_split_num_configs()), bits 8.. = K split (as in
- * cm_conv3x3: the output is zeroed and accumulated with float atomics; not with an in-place residual).         */
+ * cm_conv3x3: the output is zeroed and accumulated with float atomics; not with an in-place residual); bit 30 set =
+ * the caller has already zeroed `out` (lets it batch the fills of several launches into one).                    */
 int cm_conv3x3_split_num_configs(void);
 long long cm_conv3x3_split_packed_bytes(int k_channels, int out_channels);
 int cm_pack_conv3x3_split_batch(const void* descs_dev, int ndesc, int total_blocks, cm_stream stream);

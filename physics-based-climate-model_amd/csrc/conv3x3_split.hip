@@ -37,6 +37,7 @@ struct SplitArgs {
   int N, H, W, Cout, CoutP, nsteps, tiles_x, tiles_y;   // nsteps = 16-channel k-steps (= LDS stages)
   int dbg;     // diagnostic ablation bits (CM_CONVS_DBG): 1 skip global loads, 2 skip MFMA phase, 8 skip convert+store
   int ksplit;  // > 1: blockIdx.z owns a share of the k-steps and accumulates into a pre-zeroed output with atomics
+  int prezeroed;   // the caller already zeroed `out` (one fill for several launches): skip the internal zero launch
 };
 
 // 4-wave workgroups with one 32x32 tile per wave sit 2 registers above the 3-waves-per-SIMD allocation (170 of 168):
@@ -379,7 +380,7 @@ int launch_s(const SplitArgs& a0, hipStream_t st) {
   a.tiles_y = cdiv(a.H, c.th);
   if (a.ksplit > a.nsteps) a.ksplit = a.nsteps;
   if (a.ksplit < 1) a.ksplit = 1;
-  if (a.ksplit > 1) {
+  if (a.ksplit > 1 && !a.prezeroed) {
     const long long per = (long long)a.Cout * a.H * a.W;
     const long long zb = ((long long)a.N * per + 255) / 256;
     zero_out_split_kernel<<<(int)(zb > 2048 ? 2048 : zb), 256, 0, st>>>(a.out, a.sto, a.N, per);
@@ -458,6 +459,8 @@ int cm_conv3x3_split(const float* in0, long long st0, int c0, const float* in1, 
   a.nsteps = (c0 + c1 + SKC - 1) / SKC;
   static const int s_dbg = getenv("CM_CONVS_DBG") ? atoi(getenv("CM_CONVS_DBG")) : 0;
   a.dbg = s_dbg;
+  a.prezeroed = (config >> 30) & 1;          // bit 30: `out` is already zero (caller batches the fills)
+  config &= ~(1 << 30);
   a.ksplit = config >> 8;                    // bits 8.. = K split over blockIdx.z (0/1 = none)
   config &= 0xff;
   if (a.ksplit > 1 && resid == out) return -22;   // the in-place residual would be zeroed

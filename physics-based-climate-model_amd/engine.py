@@ -394,11 +394,13 @@ def backward(p: Params, pk, g: Params, sv: Saved, dpred: Optional[Tensor], need_
     h8, w8 = hprev.shape[3], hprev.shape[4]
     dc = torch.empty(B, ch, h8, w8, device=dev, dtype=torch.float32)
     dhrec = None
+    # the recurrent data gradients are tiny K-split launches: one zero fill for all T-1 outputs instead of one each
+    dh_all = _zeros(max(T - 1, 1), B, ch, h8, w8, device=dev)
     for t in range(T - 1, -1, -1):
         ops.lstm_gates_bwd(gx[:, t], call[:, t - 1] if t > 0 else None, call[:, t], dbott if t == T - 1 else None,
                            dhrec, dc, first=(t == T - 1))
         if t > 0:
-            dhrec = pk.conv("lstm.h/d", gx[:, t], ch)
+            dhrec = pk.conv("lstm.h/d", gx[:, t], ch, out=dh_all[t - 1], out_zeroed=True)
     dA = gx.view(B * T, 4 * ch, h8, w8)            # now holds d(pre-activations) for every (b, t)
     gl = gw["convlstm.cell.conv.weight"]
 

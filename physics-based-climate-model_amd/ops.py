@@ -115,12 +115,14 @@ SMALLC_CFG = 1 << 22   # tuned configuration id of the few-input-channels kernel
 LAST_CONV_CONFIG = -1   # configuration the most recent conv3x3() call ran with (the engine prunes unused weight packs)
 
 
-def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1, wps=None, w_raw=None):
+def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1, wps=None, w_raw=None,
+            out_zeroed=False):
     """out = conv3x3(cat(x0, x1), wp) + bias + resid.  x0/x1: [N,C,H,W] (sample stride may exceed C*H*W).
 
     ``wp`` is the fp32-MFMA operand (cm_pack_conv3x3); ``wps`` (optional) the bf16x6 operand of the same weight;
     ``w_raw`` (optional) the unpacked [cout, cin, 3, 3] parameter, which adds the few-input-channels kernel
-    (cm_conv3x3_smallc) to the candidates when cin * 9 <= 64.
+    (cm_conv3x3_smallc) to the candidates when cin * 9 <= 64.  ``out_zeroed``: the caller has filled ``out`` with
+    zeros (one fill for several launches), so a K-split bf16x6 launch skips its own zero-fill launch.
     With config < 0 the autotuner times both kernel families on this call signature and keeps the faster one."""
     n, c0, h, w = x0.shape
     c1 = 0 if x1 is None else x1.shape[1]
@@ -172,9 +174,12 @@ def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1, w
                                     _stream()), "conv3x3_smallc")
         return out
     if config >= SPLIT_BASE:
+        cfg = config - SPLIT_BASE
+        if out_zeroed and (cfg >> 8) > 1:
+            cfg |= 1 << 30
         check(lib.cm_conv3x3_split(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(wps), _p(bias), _p(resid),
                                    0 if resid is None else resid.stride(0), _p(out), out.stride(0), n, h, w, cout,
-                                   config - SPLIT_BASE, _stream()), "conv3x3_split")
+                                   cfg, _stream()), "conv3x3_split")
         return out
     check(lib.cm_conv3x3(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(wp), _p(bias),
                          _p(resid), 0 if resid is None else resid.stride(0), _p(out), out.stride(0), n, h, w, cout,
