@@ -28,7 +28,7 @@ struct FcArgs {
 };
 
 template <int KS2>   // k-steps of two: ceil(Cin * 9 / 2) <= KS2
-__global__ __launch_bounds__(256, 3) void conv3x3_smallc_kernel(FcArgs a) {
+__global__ __launch_bounds__(256, 3) void conv3x3_smallc_kernel(FcArgs a) {   // (256 threads, >= 3 waves per EU)
   extern __shared__ float sh[];
   const int W = a.W, H = a.H, HW = H * W, R = a.R, Cin = a.Cin, K = Cin * 9;
   const int PW = W + 2, XROWS = R + 2, XPL = XROWS * PW;

@@ -40,14 +40,13 @@ struct SplitArgs {
   int prezeroed;   // the caller already zeroed `out` (one fill for several launches): skip the internal zero launch
 };
 
-// 4-wave workgroups with one 32x32 tile per wave sit 2 registers above the 3-waves-per-SIMD allocation (170 of 168):
-// ask for three resident workgroups so that the allocator trims them (LDS allows three: <= 53 KB each).
-constexpr int split_min_blocks(int waves, int npt, int wm) {
-  return (npt * wm == 1 && waves == 4) ? 3 : 1;   // -> 12 waves per CU = 3 per SIMD
-}
+// Workgroups with one 32x32 tile per wave sit 2 registers above the 3-waves-per-SIMD allocation (170 of 168): ask for
+// three waves per SIMD (hip-clang's second __launch_bounds__ argument is MIN WAVES PER EU) so that the allocator trims
+// them; LDS allows three 4-wave workgroups per CU (<= 53 KB each).
+constexpr int split_min_waves(int waves, int npt, int wm) { return (npt * wm == 1 && waves == 4) ? 3 : 1; }
 
 template <int TH, int TW, int S, int WAVES, int NPT, int WM, bool DUAL>
-__global__ __launch_bounds__(WAVES * 64, split_min_blocks(WAVES, NPT, WM)) void conv3x3_split_kernel(SplitArgs a) {
+__global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void conv3x3_split_kernel(SplitArgs a) {
   constexpr int THREADS = WAVES * 64;
   constexpr int PITCH = TW + 2;
   constexpr int SS = (TH + 2) * PITCH;

@@ -52,11 +52,12 @@ struct WsGeom {
 };
 
 // LEAN form (KS = 2, MO = 1): no conversion in the MFMA shadow and no fragment ping-pong, which brings the kernel under
-// 168 registers so that TWO 6-wave workgroups share a CU (3 waves per SIMD instead of 1.5).
+// 168 registers so that TWO 6-wave workgroups share a CU (3 waves per SIMD instead of 1.5; the second
+// __launch_bounds__ argument is hip-clang's MIN WAVES PER EU).
 constexpr bool ws_lean(int mo, int ks) { return mo == 1 && ks == 2; }
 
 template <int TW, int MO, int KS, bool DUAL>
-__global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 2 : 1) void wgrad3x3_split_kernel(WsArgs a) {
+__global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 3 : 1) void wgrad3x3_split_kernel(WsArgs a) {
   using G = WsGeom<TW, MO, KS>;
   constexpr int THREADS = 192 * KS;
   constexpr int NPAIR = G::NPAIR, XP = G::XP, DP = G::DP, BCO = G::BCO, XSLOT = G::XSLOT;
