@@ -296,6 +296,33 @@ class _SideStream:
 # workgroups do not co-reside with the conv workgroups, so the two kernels time-slice the CUs), hence off by default.
 OVERLAP_WGRAD = os.environ.get("CM_OVERLAP_WGRAD", "0") != "0"
 
+# The ConvLSTM recurrence is a serial chain of small launches (N = B samples at 6x9: <= 256 workgroups each) that leaves
+# most of the chip idle.  Work that does not depend on it runs beside it on the side stream: the three time-mean
+# skips in the forward, the decoder's (deferred) weight gradients in the backward.
+OVERLAP_LSTM = os.environ.get("CM_OVERLAP_LSTM", "1") != "0"
+
+
+class _Deferred:
+    """Collects launches (same ``run`` interface as _SideStream) to be issued later in one go."""
+
+    def __init__(self, enabled: bool):
+        self.enabled = enabled
+        self.jobs = []
+        self.keep = []
+
+    def run(self, fn, *tensors):
+        if not self.enabled:
+            fn()
+            return
+        self.jobs.append(fn)
+        self.keep.extend(t for t in tensors if t is not None)
+
+    def flush(self):
+        for fn in self.jobs:
+            fn()
+        self.jobs.clear()
+        self.keep.clear()
+
 
 class Saved:
     """Everything the backward needs from one forward."""
@@ -332,6 +359,9 @@ def forward(p: Params, pk, x_seq: Tensor, save: bool = True, head: bool = True):
     hprev = _zeros(B, T, ch, h8, w8, device=x.device)       # hprev[:, t] = h_{t-1}; slot 0 stays 0
     call = torch.empty(B, T, ch, h8, w8, device=x.device, dtype=torch.float32)
     bott = torch.empty(B, ch, h8, w8, device=x.device, dtype=torch.float32)
+    skips = []
+    side = _SideStream(x.device, OVERLAP_LSTM)
+    side.run(lambda: skips.extend(ops.time_mean(sk, B, T) for sk in (s1, s2, s3)), s1, s2, s3)   # beside the recurrence
     for t in range(T):
         if t > 0:
             pk.conv("lstm.h/f", hprev[:, t], 4 * ch, resid=gx[:, t], out=gx[:, t])
@@ -339,7 +369,8 @@ def forward(p: Params, pk, x_seq: Tensor, save: bool = True, head: bool = True):
                            hprev[:, t + 1] if t + 1 < T else bott)
 
     # ---- time-mean skips + decoder ---------------------------------------------------------------------
-    k1, k2, k3 = ops.time_mean(s1, B, T), ops.time_mean(s2, B, T), ops.time_mean(s3, B, T)
+    side.join()
+    k1, k2, k3 = skips
     u3 = ops.convT2x2_fwd(bott, p["up3.up.weight"], p["up3.up.bias"])
     d3, cu3 = _block_fwd(p, pk, "up3.conv.", u3, k3, save)
     u2 = ops.convT2x2_fwd(d3, p["up2.up.weight"], p["up2.up.bias"])
@@ -377,13 +408,15 @@ def backward(p: Params, pk, g: Params, sv: Saved, dpred: Optional[Tensor], need_
     # ---- head + decoder --------------------------------------------------------------------------------
     if dd1 is None:
         dd1 = ops.head_bwd(dpred, sv.d1, p["head.weight"], g["head.weight"], g["head.bias"])
-    dcat1 = _block_bwd(p, pk, g, gw, ss, "up1.conv.", cu1, dd1)
+    dec = _Deferred(OVERLAP_LSTM and not OVERLAP_WGRAD)      # decoder weight gradients: issued beside the LSTM chain
+    dss = dec if dec.enabled else ss
+    dcat1 = _block_bwd(p, pk, g, gw, dss, "up1.conv.", cu1, dd1)
     b1 = cu1.x0.shape[1]
     dd2 = ops.convT2x2_bwd(d2, p["up1.up.weight"], dcat1[:, :b1], g["up1.up.weight"], g["up1.up.bias"])
-    dcat2 = _block_bwd(p, pk, g, gw, ss, "up2.conv.", cu2, dd2)
+    dcat2 = _block_bwd(p, pk, g, gw, dss, "up2.conv.", cu2, dd2)
     b2 = cu2.x0.shape[1]
     dd3 = ops.convT2x2_bwd(d3, p["up2.up.weight"], dcat2[:, :b2], g["up2.up.weight"], g["up2.up.bias"])
-    dcat3 = _block_bwd(p, pk, g, gw, ss, "up3.conv.", cu3, dd3)
+    dcat3 = _block_bwd(p, pk, g, gw, dss, "up3.conv.", cu3, dd3)
     b3 = cu3.x0.shape[1]
     dbott = ops.convT2x2_bwd(bott, p["up3.up.weight"], dcat3[:, :b3], g["up3.up.weight"], g["up3.up.bias"])
 
@@ -396,6 +429,8 @@ def backward(p: Params, pk, g: Params, sv: Saved, dpred: Optional[Tensor], need_
     dhrec = None
     # the recurrent data gradients are tiny K-split launches: one zero fill for all T-1 outputs instead of one each
     dh_all = _zeros(max(T - 1, 1), B, ch, h8, w8, device=dev)
+    side = _SideStream(dev, dec.enabled)
+    side.run(dec.flush, *list(dec.keep))      # (the side stream keeps the operands alive until its join)
     for t in range(T - 1, -1, -1):
         ops.lstm_gates_bwd(gx[:, t], call[:, t - 1] if t > 0 else None, call[:, t], dbott if t == T - 1 else None,
                            dhrec, dc, first=(t == T - 1))
@@ -421,5 +456,6 @@ def backward(p: Params, pk, g: Params, sv: Saved, dpred: Optional[Tensor], need_
     ds1 = ops.maxpool2_bwd(c1.out, dp1, dcat1[:, b1:], t=T)
     dx = _block_bwd(p, pk, g, gw, ss, "enc1.", c1, ds1, need_dx=need_dx)
     ss.join()
+    side.join()
     plan.unpack()
     return dx.view(sv.x_shape) if dx is not None else None
