@@ -292,14 +292,21 @@ class _SideStream:
         self.keep.clear()
 
 
-# Measured on MI355X (config 2): overlapping is 5 % SLOWER than the serial chain (the 12-wave, ~100 KB-LDS weight-gradient
-# workgroups do not co-reside with the conv workgroups, so the two kernels time-slice the CUs), hence off by default.
+# Both side-stream overlaps are OFF by default.  Round-1 findings on MI355X (config 2):
+#  * performance: with the fp32 weight-gradient kernel (12 waves, ~100 KB LDS per workgroup) overlapping all weight
+#    gradients with the data-gradient chain was 5 % slower (the kernels time-slice the CUs); with the bf16x6 kernels
+#    (3-/6-wave workgroups, <= 77 KB) it measured 0-4 % faster depending on the box;
+#  * correctness: in EAGER mode with the bf16x6 weight-gradient kernel co-resident on the CUs, the main chain produced
+#    non-finite values from the second step on (first bad tensor: dpool of the 12x18 encoder block's SE backward) --
+#    even with the side kernel's global writes disabled (CM_WGS_DBG=4), never with the fp32 kernel or the 9-wave
+#    configuration that owns a CU alone, never serially.  tools/dbg_overlap.py reproduces it.  Until that is understood
+#    the serial schedule is the only supported one; CM_OVERLAP_WGRAD=1 / CM_OVERLAP_LSTM=1 are for investigation.
 OVERLAP_WGRAD = os.environ.get("CM_OVERLAP_WGRAD", "0") != "0"
 
 # The ConvLSTM recurrence is a serial chain of small launches (N = B samples at 6x9: <= 256 workgroups each) that leaves
-# most of the chip idle.  Work that does not depend on it runs beside it on the side stream: the three time-mean
-# skips in the forward, the decoder's (deferred) weight gradients in the backward.
-OVERLAP_LSTM = os.environ.get("CM_OVERLAP_LSTM", "1") != "0"
+# most of the chip idle.  Work that does not depend on it can run beside it on the side stream: the three time-mean
+# skips in the forward, the decoder's (deferred) weight gradients in the backward (~0.5 % of the step).
+OVERLAP_LSTM = os.environ.get("CM_OVERLAP_LSTM", "0") != "0"
 
 
 class _Deferred:

@@ -250,7 +250,10 @@ def wgrad3x3(x0, dy, g, c_off=0, x1=None, config=-1):
             return _wgrad_call(x0, dy, _scratch[0], c_off, x1, cfg)
         cands = [c + (u << 8) for c in range(lib.cm_wgrad3x3_num_configs()) for u in (2, 3, 4, 6, 8)]
         if WGRAD_BF16X6 and (c1 == 0 or c0 % 32 == 0):
-            cands += [SPLIT_BASE + c + (u << 8) for c in range(lib.cm_wgrad3x3_split_num_configs()) for u in (2, 4, 8)]
+            only = os.environ.get("CM_WGS_ONLY")        # diagnostic: restrict to one bf16x6 configuration
+            ids = [int(only)] if only else range(lib.cm_wgrad3x3_split_num_configs())
+            split = [SPLIT_BASE + c + (u << 8) for c in ids for u in (2, 4, 8)]
+            cands = split if only else cands + split
         if c1 == 0 and c0 * 9 <= 64 and w % 4 == 0 and w <= 320 and dy.stride(0) % 4 == 0:
             cands.append(SMALLC_CFG)
         config = _pick(("wgrad3x3", n, h, w, c0, c1, cout, WGRAD_BF16X6), cands, launch, -1)
