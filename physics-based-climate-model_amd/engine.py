@@ -296,11 +296,15 @@ class _SideStream:
 #  * performance: with the fp32 weight-gradient kernel (12 waves, ~100 KB LDS per workgroup) overlapping all weight
 #    gradients with the data-gradient chain was 5 % slower (the kernels time-slice the CUs); with the bf16x6 kernels
 #    (3-/6-wave workgroups, <= 77 KB) it measured 0-4 % faster depending on the box;
-#  * correctness: in EAGER mode with the bf16x6 weight-gradient kernel co-resident on the CUs, the main chain produced
-#    non-finite values from the second step on (first bad tensor: dpool of the 12x18 encoder block's SE backward) --
-#    even with the side kernel's global writes disabled (CM_WGS_DBG=4), never with the fp32 kernel or the 9-wave
-#    configuration that owns a CU alone, never serially.  tools/dbg_overlap.py reproduces it.  Until that is understood
-#    the serial schedule is the only supported one; CM_OVERLAP_WGRAD=1 / CM_OVERLAP_LSTM=1 are for investigation.
+#  * correctness: in EAGER mode with bf16x6 weight-gradient workgroups co-resident on the CUs, the main chain produced
+#    non-finite values from the second step on.  Traced (tools/dbg_overlap.py) to ONE lost amax tie count: the gate
+#    backward read the SE scale `s` through the scalar cache and got the PREVIOUS step's values (same address, equal up
+#    to rounding), so no channel matched the stored maximum, cnt = 0, division by zero downstream.  Turning that one
+#    read into a vector load removed the failure in 3 of 3 runs -- i.e. with two queues active the scalar cache can
+#    serve stale lines of memory rewritten by earlier kernels of the same queue.  Every kernel here reads small
+#    device-written tensors (statistics, scales, parameters updated by Adam) through uniform loads, so until all of
+#    them are audited the serial schedule is the only supported one; CM_OVERLAP_WGRAD=1 / CM_OVERLAP_LSTM=1 are for
+#    investigation.
 OVERLAP_WGRAD = os.environ.get("CM_OVERLAP_WGRAD", "0") != "0"
 
 # The ConvLSTM recurrence is a serial chain of small launches (N = B samples at 6x9: <= 256 workgroups each) that leaves

@@ -34,6 +34,9 @@ for it in range(2):
     print("iter", it, "loss", tr.loss.item(), "non-finite grads:", len(bad))
     for i, (name, outs, shp) in enumerate(log):
         nf = [j for j, t in enumerate(outs) if not torch.isfinite(t).all()]
+        if name == "gates_bwd" and (outs[1] == 0).any():
+            print(f"   op #{i} gates_bwd: cnt == 0 at {(outs[1] == 0).sum().item()} pixels (tie count lost: the tie test "
+                  f"saw different a2 / s / max values than the forward stored)")
         if nf:
             print(f"   first non-finite output: op #{i} {name} outputs {nf} arg shapes {shp}; previous ops:",
                   [l[0] for l in log[max(0, i - 4):i]])
