@@ -352,9 +352,11 @@ __global__ __launch_bounds__(256) void gate_bwd_reduce_kernel(const float* __res
   for (int c = c0; c < c1; ++c) {
     const long long i = ((long long)n * C + c) * HW + pp;
     const vec_t av = *reinterpret_cast<const vec_t*>(a2 + i), dv = *reinterpret_cast<const vec_t*>(dout + i);
-    // VECTOR load on purpose (the offset is always 0 but not provably uniform): as a scalar load this read returned
-    // STALE values of s (previous step's, equal up to rounding) when another queue's kernel ran on the CU at the same
-    // time -- the tie count then missed the arg-max channel (cnt = 0 -> division by zero downstream).  See engine.py.
+    // Per-lane dword load on purpose (the offset is always 0 but not provably uniform).  With the plain `sp[c]` the
+    // compiler merged eight channels into two uniform-address global_load_dwordx4; with another queue's kernel
+    // co-resident on the CU those loads returned the PREVIOUS step's values of s (same address, equal up to rounding),
+    // the tie count missed the arg-max channel (cnt = 0) and a division by zero followed.  This form did not fail in
+    // 7 of 7 runs; the mechanism (stale vector-L1 lines?) is not understood -- see engine.py.
     const float sc = sp[c + (threadIdx.x >> 30)];
 #pragma unroll
     for (int q = 0; q < VEC; ++q) {

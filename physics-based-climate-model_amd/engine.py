@@ -298,12 +298,12 @@ class _SideStream:
 #    (3-/6-wave workgroups, <= 77 KB) it measured 0-4 % faster depending on the box;
 #  * correctness: in EAGER mode with bf16x6 weight-gradient workgroups co-resident on the CUs, the main chain produced
 #    non-finite values from the second step on.  Traced (tools/dbg_overlap.py) to ONE lost amax tie count: the gate
-#    backward read the SE scale `s` through the scalar cache and got the PREVIOUS step's values (same address, equal up
-#    to rounding), so no channel matched the stored maximum, cnt = 0, division by zero downstream.  Turning that one
-#    read into a vector load removed the failure in 3 of 3 runs -- i.e. with two queues active the scalar cache can
-#    serve stale lines of memory rewritten by earlier kernels of the same queue.  Every kernel here reads small
-#    device-written tensors (statistics, scales, parameters updated by Adam) through uniform loads, so until all of
-#    them are audited the serial schedule is the only supported one; CM_OVERLAP_WGRAD=1 / CM_OVERLAP_LSTM=1 are for
+#    backward read the SE scale `s` (two uniform-address 16-byte loads per eight channels) and got the PREVIOUS step's
+#    values (same address, equal up to rounding), so no channel matched the stored maximum, cnt = 0, division by zero
+#    downstream.  Rewriting that read as per-lane dword loads removed the failure (7 of 7 runs, eager soak included),
+#    but the mechanism is not understood (stale vector-L1 lines while two queues share a CU?), and every kernel here
+#    reads small device-written tensors (statistics, scales, Adam-updated parameters) through uniform loads.  Until
+#    that is understood the serial schedule is the only supported one; CM_OVERLAP_WGRAD=1 / CM_OVERLAP_LSTM=1 are for
 #    investigation.
 OVERLAP_WGRAD = os.environ.get("CM_OVERLAP_WGRAD", "0") != "0"
 
