@@ -106,16 +106,20 @@ int cm_gn_silu_fwd(const float* x, const float* gamma, const float* beta, float*
 int cm_gn_silu_bwd(const float* x, const float* gamma, const float* beta, const float* stats, const float* dA,
                    long long st_dA, float* dx, float* dgamma, float* dbeta, int n, int c, int hw, int groups,
                    cm_stream stream);
-/* same, with the gradient wrt y rebuilt on the fly from the SE / spatial-gate backward maps (see below). */
-/* y = SiLU(GroupNorm(x)) from the stored statistics of cm_gn_silu_fwd.  cm_gn_silu_bwd_gated recomputes the forward
- * activation this way instead of reading `a2` back (its `a2` argument is unused and may be NULL); the result is
- * bit-identical to what cm_gn_silu_fwd wrote, which the amax tie test depends on. */
+/* y = SiLU(GroupNorm(x)) from the stored statistics of cm_gn_silu_fwd: the recomputation cm_gn_silu_bwd_gated performs
+ * inline; bit-identical to what cm_gn_silu_fwd wrote, which the amax tie test depends on. */
 int cm_gn_silu_apply(const float* x, const float* gamma, const float* beta, const float* stats, float* y, int n, int c,
                      int hw, int groups, cm_stream stream);
+/* cm_gn_silu_bwd with the gradient wrt y rebuilt on the fly from the SE / spatial-gate backward maps (see below).
+ * `a2` is unused (recomputed; may be NULL).  Optional side duty (se_dsig != NULL): the SE weight gradients of the
+ * preceding cm_se_excite_bwd call -- dw2 [c,cr] += dsig^T relu(z), dw1 [cr,c] += dz^T pooled -- computed by this
+ * launch's workgroups, which saves the separate launch (call cm_se_excite_bwd with dw1 = dw2 = NULL then). */
 int cm_gn_silu_bwd_gated(const float* x, const float* gamma, const float* beta, const float* stats,
                          const float* a2, const float* dout, const float* gate, const float* dmap, const float* fmap,
                          const float* cnt, const float* s, const float* dpool, float* dx, float* dgamma,
-                         float* dbeta, int n, int c, int hw, int groups, cm_stream stream);
+                         float* dbeta, int n, int c, int hw, int groups, const float* se_dsig, const float* se_dz,
+                         const float* se_z, const float* se_pooled, float* se_dw1, float* se_dw2, int se_cr,
+                         cm_stream stream);
 
 /* ---- SE channel gate + CBAM spatial gate ------------------------------------------------------------------- *
  * SEBlock src/unet.py:6-17, SpatialGate src/unet.py:19-29.  a2 [n,c,hw] = activation entering SE; s [n,c] SE scale;
@@ -144,7 +148,8 @@ int cm_conv7_bwd(const float* dgpre, const float* map, const float* w7, float* d
 int cm_se_bwd_reduce(const float* dout, const float* a2, const float* s, const float* gate, const float* dmap,
                      const float* map, const float* cnt, float* ds, int n, int c, int hw, const float* c7_partials,
                      int c7_rows, float* dw7, cm_stream stream);
-/* dsig [n,c], dz [n,cr], dpool [n,c] are outputs; dw1 [cr,c], dw2 [c,cr] are ACCUMULATED. */
+/* dsig [n,c], dz [n,cr], dpool [n,c] are outputs; dw1 [cr,c], dw2 [c,cr] are ACCUMULATED (both NULL: left to the side
+ * duty of cm_gn_silu_bwd_gated). */
 int cm_se_excite_bwd(const float* ds, const float* s, const float* z, const float* pooled, const float* w1,
                      const float* w2, float* dsig, float* dz, float* dpool, float* dw1, float* dw2, int n, int c,
                      int cr, cm_stream stream);

@@ -8,6 +8,7 @@
 // Backward facts pinned by the golden fixtures: amax splits its gradient EQUALLY among tied channels (so the tie
 // count map `cnt` is built from the bit-exact product a2*s), mean_c spreads 1/C.
 #include "common.h"
+#include "se_wgrad.h"
 #include "../../include/climate_hip.h"
 
 namespace {
@@ -79,35 +80,10 @@ __global__ __launch_bounds__(256) void se_excite_bwd_kernel(const float* __restr
   }
 }
 
-// dW2[c][r] += sum_n dsig[n,c] relu(z[n,r]);  dW1[r][c] += sum_n dz[n,r] pooled[n,c]
-// 32 weights x 8 sample-slices per workgroup, slices combined through LDS (deterministic order).
-__global__ __launch_bounds__(256) void se_wgrad_kernel(const float* __restrict__ dsig, const float* __restrict__ dz,
-                                                        const float* __restrict__ z,
-                                                        const float* __restrict__ pooled, float* __restrict__ dw1,
-                                                        float* __restrict__ dw2, int N, int C, int Cr) {
+// stand-alone launch of the SE weight gradients (se_wgrad.h); the engine normally lets the gated GroupNorm backward do it
+__global__ __launch_bounds__(256) void se_wgrad_kernel(SeWgradArgs a) {
   __shared__ float part[8][33];
-  const int wl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int i = blockIdx.x * 32 + wl;
-  const int total = 2 * C * Cr;
-  float a = 0.f;
-  if (i < total) {
-    if (i < C * Cr) {  // dW2[c][r]
-      const int c = i / Cr, r = i % Cr;
-      for (int n = sl; n < N; n += 8) a += dsig[(long long)n * C + c] * fmaxf(z[(long long)n * Cr + r], 0.f);
-    } else {           // dW1[r][c]
-      const int j = i - C * Cr;
-      const int r = j / C, c = j % C;
-      for (int n = sl; n < N; n += 8) a += dz[(long long)n * Cr + r] * pooled[(long long)n * C + c];
-    }
-  }
-  part[sl][wl] = a;
-  __syncthreads();
-  if (sl == 0 && i < total) {
-    float t = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) t += part[k][wl];
-    if (i < C * Cr) dw2[i] += t; else dw1[i - C * Cr] += t;
-  }
+  se_wgrad_chunk(a, blockIdx.x, part);
 }
 
 // ------------------------------------------------------------------------------------------------ spatial gate fwd
@@ -578,8 +554,12 @@ int cm_se_excite_bwd(const float* ds, const float* s, const float* z, const floa
   se_excite_bwd_kernel<<<n, 256, (c + cr) * sizeof(float), (hipStream_t)stream>>>(ds, s, z, w1, w2, dsig, dz, dpool,
                                                                                    c, cr);
   CM_CHECK_LAUNCH();
-  se_wgrad_kernel<<<cdiv(2 * c * cr, 32), 256, 0, (hipStream_t)stream>>>(dsig, dz, z, pooled, dw1, dw2, n, c, cr);
-  CM_CHECK_LAUNCH();
+  if (dw1 && dw2) {      // (NULL: the caller hands the weight gradients to cm_gn_silu_bwd_gated as a side duty)
+    SeWgradArgs wa;
+    wa.dsig = dsig; wa.dz = dz; wa.z = z; wa.pooled = pooled; wa.dw1 = dw1; wa.dw2 = dw2; wa.N = n; wa.C = c; wa.Cr = cr;
+    se_wgrad_kernel<<<cdiv(2 * c * cr, 32), 256, 0, (hipStream_t)stream>>>(wa);
+    CM_CHECK_LAUNCH();
+  }
   return 0;
 }
 

@@ -11,6 +11,7 @@
 // fp32 so they stay within ~1e-7 of torch's CPU result.
 #include <stdlib.h>
 #include "common.h"
+#include "se_wgrad.h"
 #include "../../include/climate_hip.h"
 
 namespace {
@@ -152,6 +153,7 @@ struct GateBwd {
   const float* cnt;    // [N,HW]    number of channels attaining the max
   const float* s;      // [N,C]     SE scale
   const float* dpool;  // [N,C]     gradient wrt the SE squeeze (pooled mean)
+  SeWgradArgs se;      // side duty: the SE weight gradients of the preceding cm_se_excite_bwd (se.dsig NULL: none)
 };
 
 // Backward, one workgroup per (sample, group), one wave per channel.
@@ -168,6 +170,10 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_kernel(const float* __
                                                                    float* __restrict__ dgamma,
                                                                    float* __restrict__ dbeta, int C, int HW, int G) {
   __shared__ float acc[2];
+  if (MODE == 1 && gb.se.dsig) {     // side duty (saves a launch): 32 SE weights per chunk, chunks strided over the grid
+    __shared__ float part[8][33];
+    for (int ch = blockIdx.x; ch * 32 < 2 * gb.se.C * gb.se.Cr; ch += gridDim.x) se_wgrad_chunk(gb.se, ch, part);
+  }
   const int n = blockIdx.x / G, g = blockIdx.x % G;
   const int cpg = C / G;
   const int tid = threadIdx.x, lane = tid % LPC, wave = tid / LPC;
@@ -346,6 +352,10 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_reg_kernel(const float
                                                                        float* __restrict__ dgamma,
                                                                        float* __restrict__ dbeta, int C, int HW, int G) {
   __shared__ float csd[64], csdx[64], tot[2];
+  if (MODE == 1 && gb.se.dsig) {     // side duty (saves a launch): 32 SE weights per chunk, chunks strided over the grid
+    __shared__ float part[8][33];
+    for (int ch = blockIdx.x; ch * 32 < 2 * gb.se.C * gb.se.Cr; ch += gridDim.x) se_wgrad_chunk(gb.se, ch, part);
+  }
   const int n = blockIdx.x / G, g = blockIdx.x % G;
   const int cpg = C / G;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -526,10 +536,15 @@ int cm_gn_silu_apply(const float* x, const float* gamma, const float* beta, cons
 int cm_gn_silu_bwd_gated(const float* x, const float* gamma, const float* beta, const float* stats,
                          const float* a2, const float* dout, const float* gate, const float* dmap, const float* fmap,
                          const float* cnt, const float* s, const float* dpool, float* dx, float* dgamma,
-                         float* dbeta, int n, int c, int hw, int groups, cm_stream stream) {
+                         float* dbeta, int n, int c, int hw, int groups, const float* se_dsig, const float* se_dz,
+                         const float* se_z, const float* se_pooled, float* se_dw1, float* se_dw2, int se_cr,
+                         cm_stream stream) {
   if (n <= 0 || c <= 0 || hw <= 0 || groups <= 0 || c % groups) return -22;
+  if (se_dsig && (!se_dz || !se_z || !se_pooled || !se_dw1 || !se_dw2 || se_cr <= 0)) return -22;
   GateBwd gb;
   gb.a2 = a2; gb.dout = dout; gb.gate = gate; gb.dmap = dmap; gb.umax = fmap; gb.cnt = cnt; gb.s = s; gb.dpool = dpool;
+  gb.se.dsig = se_dsig; gb.se.dz = se_dz; gb.se.z = se_z; gb.se.pooled = se_pooled; gb.se.dw1 = se_dw1; gb.se.dw2 = se_dw2;
+  gb.se.N = n; gb.se.C = c; gb.se.Cr = se_cr;
   const bool vec = (hw % 4) == 0;
   const bool narrow = (vec ? hw / 4 : hw) <= 64 && (c / groups) >= 8;
   hipStream_t st = (hipStream_t)stream;

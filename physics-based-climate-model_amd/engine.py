@@ -221,12 +221,14 @@ def _block_bwd(p: Params, pk, g: Params, gw: Params, ss: "_SideStream", prefix: 
     """Returns d(input) as one tensor [N, C0+C1, H, W] (or None); parameter gradients are accumulated into ``g``."""
     co = ctx.y1.shape[1]
     w1, w2, w7 = p[prefix + "se.fc.0.weight"], p[prefix + "se.fc.2.weight"], p[prefix + "spat.conv.weight"]
-    dmap, cnt, dpool = ops.gates_bwd(dout, ctx.a2, ctx.s, ctx.z, ctx.pooled, ctx.gate, ctx.fmap, w1, w2, w7,
-                                     g[prefix + "se.fc.0.weight"], g[prefix + "se.fc.2.weight"],
-                                     g[prefix + "spat.conv.weight"])
+    dmap, cnt, dpool, (dsig, dz) = ops.gates_bwd(dout, ctx.a2, ctx.s, ctx.z, ctx.pooled, ctx.gate, ctx.fmap, w1, w2, w7,
+                                                 g[prefix + "se.fc.0.weight"], g[prefix + "se.fc.2.weight"],
+                                                 g[prefix + "spat.conv.weight"], defer_se_wgrad=True)
+    # (the SE weight gradients ride along with the GroupNorm backward launch)
     dy2 = ops.gn_silu_bwd_gated(ctx.y2, p[prefix + "body.4.weight"], p[prefix + "body.4.bias"], ctx.st2, ctx.a2, dout,
                                 ctx.gate, dmap, ctx.fmap, cnt, ctx.s, dpool, g[prefix + "body.4.weight"],
-                                g[prefix + "body.4.bias"])
+                                g[prefix + "body.4.bias"],
+                                se=(dsig, dz, ctx.z, ctx.pooled, g[prefix + "se.fc.0.weight"], g[prefix + "se.fc.2.weight"]))
     ss.run(lambda: ops.wgrad3x3(ctx.a1, dy2, gw[prefix + "body.3.weight"]), ctx.a1, dy2)
     da1 = pk.conv(prefix + "body.3.weight/d", dy2, co)
     dy1 = ops.gn_silu_bwd(ctx.y1, p[prefix + "body.1.weight"], p[prefix + "body.1.bias"], ctx.st1, da1,

@@ -296,12 +296,17 @@ def gn_silu_bwd(x, gamma, beta, stats, dA, dgamma, dbeta):
     return dx
 
 
-def gn_silu_bwd_gated(x, gamma, beta, stats, a2, dout, gate, dmap, fmap, cnt, s, dpool, dgamma, dbeta):
+def gn_silu_bwd_gated(x, gamma, beta, stats, a2, dout, gate, dmap, fmap, cnt, s, dpool, dgamma, dbeta, se=None):
+    """``se`` = (dsig, dz, z, pooled, dw1, dw2) hands the SE weight gradients of the preceding gates_bwd(...,
+    defer_se_wgrad=True) to this launch as a side duty (one launch less)."""
     n, c, h, w = x.shape
     dx = torch.empty_like(_contig(x))
+    sd = se if se is not None else (None,) * 6
+    cr = 0 if se is None else se[1].shape[1]
     check(lib.cm_gn_silu_bwd_gated(_p(x), _p(gamma), _p(beta), _p(stats), _p(a2), _p(_contig(dout)), _p(gate),
                                    _p(dmap), _p(fmap), _p(cnt), _p(s), _p(dpool), _p(dx), _p(dgamma), _p(dbeta), n, c,
-                                   h * w, GN_GROUPS, _stream()), "gn_silu_bwd_gated")
+                                   h * w, GN_GROUPS, _p(sd[0]), _p(sd[1]), _p(sd[2]), _p(sd[3]), _p(sd[4]), _p(sd[5]), cr,
+                                   _stream()), "gn_silu_bwd_gated")
     return dx
 
 
@@ -348,8 +353,9 @@ def se_spatial_gate_fwd(a2, pooled, w1, w2, w7, pool_out=False):
     return out, z, s, fmap, gate
 
 
-def gates_bwd(dout, a2, s, z, pooled, gate, fmap, w1, w2, w7, dw1, dw2, dw7):
-    """Backward of SE + spatial gate up to (but excluding) the GroupNorm; returns the maps cm_gn_silu_bwd_gated needs."""
+def gates_bwd(dout, a2, s, z, pooled, gate, fmap, w1, w2, w7, dw1, dw2, dw7, defer_se_wgrad=False):
+    """Backward of SE + spatial gate up to (but excluding) the GroupNorm; returns the maps cm_gn_silu_bwd_gated needs
+    (plus (dsig, dz) when ``defer_se_wgrad``: the SE weight gradients are then left to gn_silu_bwd_gated(se=...))."""
     n, c, h, w = a2.shape
     cr = w1.shape[0]
     dev = a2.device
@@ -369,7 +375,10 @@ def gates_bwd(dout, a2, s, z, pooled, gate, fmap, w1, w2, w7, dw1, dw2, dw7):
     check(lib.cm_se_bwd_reduce(_p(dout), _p(a2), _p(s), _p(gate), _p(dmap), _p(fmap), _p(cnt), _p(ds), n, c, h * w,
                                _p(c7ws), c7ws.numel() // 98, _p(dw7), st), "se_bwd_reduce")
     check(lib.cm_se_excite_bwd(_p(ds), _p(s), _p(z), _p(pooled), _p(_contig(w1)), _p(_contig(w2)), _p(dsig), _p(dz),
-                               _p(dpool), _p(dw1), _p(dw2), n, c, cr, st), "se_excite_bwd")
+                               _p(dpool), None if defer_se_wgrad else _p(dw1), None if defer_se_wgrad else _p(dw2), n, c,
+                               cr, st), "se_excite_bwd")
+    if defer_se_wgrad:
+        return dmap, cnt, dpool, (dsig, dz)
     return dmap, cnt, dpool
 
 

@@ -274,8 +274,10 @@ def test_se_and_spatial_gate_golden(ops):
     assert rel_l2(out, g["y"]) < TOL
 
 
-def test_conv_block_chain_golden(ops):
-    """ConvBlock forward + backward composed from the launchers vs the reference fixture (conv_block.npz)."""
+@pytest.mark.parametrize("defer", [False, True])
+def test_conv_block_chain_golden(ops, defer):
+    """ConvBlock forward + backward composed from the launchers vs the reference fixture (conv_block.npz); ``defer``:
+    the SE weight gradients ride along with the gated GroupNorm backward launch instead of their own."""
     g = load_golden("conv_block.npz")
     P = {k[2:]: dev(v) for k, v in g.items() if k.startswith("p.")}
     x, dy = dev(g["x"]), dev(g["dy"])
@@ -290,11 +292,13 @@ def test_conv_block_chain_golden(ops):
     assert rel_l2(out, g["y"]) < TOL
     # backward
     G = {k: torch.zeros_like(v) for k, v in P.items()}
-    dmap, cnt, dpool = ops.gates_bwd(dy, a2, s, z, pooled, gate, fmap, P["se.fc.0.weight"], P["se.fc.2.weight"],
-                                     P["spat.conv.weight"], G["se.fc.0.weight"], G["se.fc.2.weight"],
-                                     G["spat.conv.weight"])
+    res = ops.gates_bwd(dy, a2, s, z, pooled, gate, fmap, P["se.fc.0.weight"], P["se.fc.2.weight"],
+                        P["spat.conv.weight"], G["se.fc.0.weight"], G["se.fc.2.weight"], G["spat.conv.weight"],
+                        defer_se_wgrad=defer)
+    dmap, cnt, dpool = res[:3]
+    se = (res[3][0], res[3][1], z, pooled, G["se.fc.0.weight"], G["se.fc.2.weight"]) if defer else None
     dy2 = ops.gn_silu_bwd_gated(y2, P["body.4.weight"], P["body.4.bias"], st2, a2, dy, gate, dmap, fmap, cnt, s, dpool,
-                                G["body.4.weight"], G["body.4.bias"])
+                                G["body.4.weight"], G["body.4.bias"], se=se)
     gw = torch.zeros(co, 9, co, device="cuda")
     ops.wgrad3x3(a1, dy2, gw)
     G["body.3.weight"] = ops.wgrad3x3_unpack(gw)
