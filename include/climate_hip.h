@@ -111,11 +111,11 @@ int cm_gn_silu_bwd(const float* x, const float* gamma, const float* beta, const 
 int cm_gn_silu_apply(const float* x, const float* gamma, const float* beta, const float* stats, float* y, int n, int c,
                      int hw, int groups, cm_stream stream);
 /* cm_gn_silu_bwd with the gradient wrt y rebuilt on the fly from the SE / spatial-gate backward maps (see below).
- * `a2` is unused (recomputed; may be NULL).  Optional side duty (se_dsig != NULL): the SE weight gradients of the
+ * `a2` is unused (recomputed; may be NULL); umax / cnt [n,hw] come from cm_gate_bwd_reduce.  Optional side duty (se_dsig != NULL): the SE weight gradients of the
  * preceding cm_se_excite_bwd call -- dw2 [c,cr] += dsig^T relu(z), dw1 [cr,c] += dz^T pooled -- computed by this
  * launch's workgroups, which saves the separate launch (call cm_se_excite_bwd with dw1 = dw2 = NULL then). */
 int cm_gn_silu_bwd_gated(const float* x, const float* gamma, const float* beta, const float* stats,
-                         const float* a2, const float* dout, const float* gate, const float* dmap, const float* fmap,
+                         const float* a2, const float* dout, const float* gate, const float* dmap, const float* umax,
                          const float* cnt, const float* s, const float* dpool, float* dx, float* dgamma,
                          float* dbeta, int n, int c, int hw, int groups, const float* se_dsig, const float* se_dz,
                          const float* se_z, const float* se_pooled, float* se_dw1, float* se_dw2, int se_cr,
@@ -134,9 +134,13 @@ int cm_se_spatial_stats(const float* pooled, const float* w1, const float* w2, c
  * src/unet_convlstm_attention.py:21,25) from the same pass. */
 int cm_spatial_apply(const float* a2, const float* s, const float* map, const float* w7, float* gate, float* out,
                      float* pooled, int n, int c, int h, int w, cm_stream stream);
-/* backward chain: gate_bwd_reduce -> conv7_bwd -> se_bwd_reduce -> se_excite_bwd -> cm_gn_silu_bwd_gated */
-int cm_gate_bwd_reduce(const float* dout, const float* a2, const float* s, const float* gate, const float* map,
-                       float* dgpre, float* cnt, int n, int c, int hw, cm_stream stream);
+/* backward chain: gate_bwd_reduce -> conv7_bwd -> se_bwd_reduce -> se_excite_bwd -> cm_gn_silu_bwd_gated.
+ * amax backward (src/unet.py:27 under autograd: gradient split equally among tied channels): cm_gate_bwd_reduce
+ * re-derives umax [n,hw] = max_c(a2*s) and cnt [n,hw] = #{c: a2*s == umax} (>= 1 by construction) in ONE pass from
+ * the products it computes itself; the two consumers below test their own a2*s against THAT umax, so the tie logic
+ * does not depend on the forward's stored map being reproduced bit for bit and can never divide by zero. */
+int cm_gate_bwd_reduce(const float* dout, const float* a2, const float* s, const float* gate, float* dgpre, float* cnt,
+                       float* umax, int n, int c, int hw, cm_stream stream);
 /* `scratch`: cm_conv7_bwd_scratch_elems(n, h) floats of workspace (per-workgroup partial dW7 sums, no initialisation
  * needed): thousands of workgroups adding into the same 98 addresses serialise in the L2, so the partials are stored
  * and folded by a second tiny kernel inside the same call, or -- with dw7 = NULL -- by the following cm_se_bwd_reduce. */
@@ -146,7 +150,7 @@ int cm_conv7_bwd(const float* dgpre, const float* map, const float* w7, float* d
 /* c7_partials (nullable): the scratch of a preceding cm_conv7_bwd(..., dw7 = NULL, ...) with c7_rows =
  * n * ceil(h/8) rows; the first workgroups then also fold those partial sums into dw7 (saves the fold launch). */
 int cm_se_bwd_reduce(const float* dout, const float* a2, const float* s, const float* gate, const float* dmap,
-                     const float* map, const float* cnt, float* ds, int n, int c, int hw, const float* c7_partials,
+                     const float* umax, const float* cnt, float* ds, int n, int c, int hw, const float* c7_partials,
                      int c7_rows, float* dw7, cm_stream stream);
 /* dsig [n,c], dz [n,cr], dpool [n,c] are outputs; dw1 [cr,c], dw2 [c,cr] are ACCUMULATED (both NULL: left to the side
  * duty of cm_gn_silu_bwd_gated). */

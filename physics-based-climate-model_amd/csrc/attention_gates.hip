@@ -301,50 +301,53 @@ __global__ __launch_bounds__(256) void spatial_apply_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------ spatial gate bwd
-// per pixel: dgate = sum_c dout*U; dgpre = dgate*gate*(1-gate); cnt = #{c: U == max}
+// per pixel: dgate = sum_c dout*U; dgpre = dgate*gate*(1-gate); umax = max_c U; cnt = #{c: U == umax}
 // Workgroup = 64*VEC pixels x 4 channel slices, combined through LDS (VEC = 4: 16-byte loads on wide images).
+//
+// The tie bookkeeping of the backward is SELF-CONSISTENT: (umax, cnt) are both derived here, in one pass, from the
+// very products U = a2*s this launch computes, and the two consumers (se_bwd_reduce, the gated GroupNorm backward)
+// compare their own U against THIS umax -- never against the map the forward stored.  cnt >= 1 by construction (the
+// channel that set the running maximum counts itself), so `dmap_max / cnt` cannot divide by zero whatever the
+// forward wrote.  (Round 1 rebuilt cnt by testing a2*s against the forward's stored maximum: any disagreement
+// between the two evaluations produced cnt = 0 and non-finite gradients.)
 template <int VEC>
 __global__ __launch_bounds__(256) void gate_bwd_reduce_kernel(const float* __restrict__ dout,
                                                                const float* __restrict__ a2,
                                                                const float* __restrict__ s,
                                                                const float* __restrict__ gate,
-                                                               const float* __restrict__ map,
                                                                float* __restrict__ dgpre, float* __restrict__ cnt,
-                                                               int C, int HW) {
+                                                               float* __restrict__ umax, int C, int HW) {
   typedef float vec_t __attribute__((ext_vector_type(VEC)));
-  __shared__ float sdg[4][64 * VEC], scn[4][64 * VEC];
+  __shared__ float sdg[4][64 * VEC], scn[4][64 * VEC], smx[4][64 * VEC];
   const int n = blockIdx.y;
   const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const int p = (blockIdx.x * 64 + lane) * VEC;               // HW % VEC == 0 (host)
   const bool live = p < HW;
   const int pp = live ? p : 0;
-  const vec_t mx = *reinterpret_cast<const vec_t*>(map + ((long long)n * 2 + 1) * HW + pp);
   const float* sp = s + (long long)n * C;
   const int cper = (C + 3) / 4, c0 = slice * cper, c1 = min(C, c0 + cper);
-  vec_t dg, k;
+  vec_t dg, k, mx;
 #pragma unroll
-  for (int q = 0; q < VEC; ++q) { dg[q] = 0.f; k[q] = 0.f; }
+  for (int q = 0; q < VEC; ++q) { dg[q] = 0.f; k[q] = 0.f; mx[q] = -INFINITY; }
 #pragma unroll 8
   for (int c = c0; c < c1; ++c) {
     const long long i = ((long long)n * C + c) * HW + pp;
     const vec_t av = *reinterpret_cast<const vec_t*>(a2 + i), dv = *reinterpret_cast<const vec_t*>(dout + i);
-    // Per-lane dword load on purpose (the offset is always 0 but not provably uniform).  With the plain `sp[c]` the
-    // compiler merged eight channels into two uniform-address global_load_dwordx4; with another queue's kernel
-    // co-resident on the CU those loads returned the PREVIOUS step's values of s (same address, equal up to rounding),
-    // the tie count missed the arg-max channel (cnt = 0) and a division by zero followed.  This form did not fail in
-    // 7 of 7 runs; the mechanism (stale vector-L1 lines?) is not understood -- see engine.py.
-    const float sc = sp[c + (threadIdx.x >> 30)];
+    const float sc = sp[c];
 #pragma unroll
     for (int q = 0; q < VEC; ++q) {
       const float u = av[q] * sc;
       dg[q] += dv[q] * u;
-      k[q] += (u == mx[q]) ? 1.f : 0.f;
+      // running (max, multiplicity): a new maximum restarts the count at 1, an equal value adds 1
+      k[q] = (u > mx[q]) ? 1.f : (u == mx[q] ? k[q] + 1.f : k[q]);
+      mx[q] = fmaxf(mx[q], u);
     }
   }
 #pragma unroll
   for (int q = 0; q < VEC; ++q) {
     sdg[slice][lane * VEC + q] = dg[q];
     scn[slice][lane * VEC + q] = k[q];
+    smx[slice][lane * VEC + q] = mx[q];
   }
   __syncthreads();
   if (slice == 0 && live) {
@@ -352,10 +355,14 @@ __global__ __launch_bounds__(256) void gate_bwd_reduce_kernel(const float* __res
     for (int q = 0; q < VEC; ++q) {
       const int l = lane * VEC + q;
       const float t = ((sdg[0][l] + sdg[1][l]) + sdg[2][l]) + sdg[3][l];
-      const float kk = (scn[0][l] + scn[1][l]) + (scn[2][l] + scn[3][l]);
+      const float m = fmaxf(fmaxf(smx[0][l], smx[1][l]), fmaxf(smx[2][l], smx[3][l]));
+      float kk = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) kk += (smx[j][l] == m) ? scn[j][l] : 0.f;
       const float g = gate[(long long)n * HW + p + q];
       dgpre[(long long)n * HW + p + q] = t * g * (1.f - g);
-      cnt[(long long)n * HW + p + q] = kk;
+      cnt[(long long)n * HW + p + q] = fmaxf(kk, 1.f);      // (>= 1 already unless every U is NaN)
+      umax[(long long)n * HW + p + q] = m;
     }
   }
 }
@@ -476,15 +483,16 @@ __global__ __launch_bounds__(256) void conv7_fold_kernel(const float* __restrict
   conv7_fold(partials, nrows, rpb, dw7);
 }
 
-// ds[n,c] = sum_p dU * a2, with dU = dout*gate + dmapA/C + dmapM*[U==max]/cnt.  One wave per (n, CG channels), VEC
-// pixels per lane and load; the five per-pixel maps are loaded once for the CG channels.
+// ds[n,c] = sum_p dU * a2, with dU = dout*gate + dmapA/C + dmapM*[U==umax]/cnt.  One wave per (n, CG channels), VEC
+// pixels per lane and load; the five per-pixel maps are loaded once for the CG channels.  umax / cnt [N,HW] are the
+// pair written by gate_bwd_reduce (see there).
 template <int VEC, int CG>
 __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const float* __restrict__ dout,
                                                              const float* __restrict__ a2,
                                                              const float* __restrict__ s,
                                                              const float* __restrict__ gate,
                                                              const float* __restrict__ dmap,
-                                                             const float* __restrict__ map,
+                                                             const float* __restrict__ umax,
                                                              const float* __restrict__ cnt, float* __restrict__ ds,
                                                              int NC, int C, int HW,
                                                              const float* __restrict__ c7_partials, int c7_rows,
@@ -500,7 +508,7 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const float* __restr
   const vec_t* gp = reinterpret_cast<const vec_t*>(gate + (long long)n * HW);
   const vec_t* da = reinterpret_cast<const vec_t*>(dmap + (long long)n * 2 * HW);
   const vec_t* dm = reinterpret_cast<const vec_t*>(dmap + ((long long)n * 2 + 1) * HW);
-  const vec_t* mx = reinterpret_cast<const vec_t*>(map + ((long long)n * 2 + 1) * HW);
+  const vec_t* mx = reinterpret_cast<const vec_t*>(umax + (long long)n * HW);
   const vec_t* ct = reinterpret_cast<const vec_t*>(cnt + (long long)n * HW);
   const vec_t* dop = reinterpret_cast<const vec_t*>(dout + (long long)nc * HW);
   const vec_t* ap = reinterpret_cast<const vec_t*>(a2 + (long long)nc * HW);
@@ -624,17 +632,16 @@ int cm_spatial_apply(const float* a2, const float* s, const float* map, const fl
   return 0;
 }
 
-int cm_gate_bwd_reduce(const float* dout, const float* a2, const float* s, const float* gate, const float* map,
-                       float* dgpre, float* cnt, int n, int c, int hw, cm_stream stream) {
-  if (n <= 0 || c <= 0 || hw <= 0) return -22;
-  const bool wide = hw % 4 == 0 && (((uintptr_t)dout | (uintptr_t)a2 | (uintptr_t)map) & 15) == 0 &&
-                    (long long)n * (hw / 256) >= 1024;
+int cm_gate_bwd_reduce(const float* dout, const float* a2, const float* s, const float* gate, float* dgpre,
+                       float* cnt, float* umax, int n, int c, int hw, cm_stream stream) {
+  if (n <= 0 || c <= 0 || hw <= 0 || !cnt || !umax) return -22;
+  const bool wide = hw % 4 == 0 && (((uintptr_t)dout | (uintptr_t)a2) & 15) == 0 && (long long)n * (hw / 256) >= 1024;
   if (wide)
-    gate_bwd_reduce_kernel<4><<<dim3(cdiv(hw, 256), n), 256, 0, (hipStream_t)stream>>>(dout, a2, s, gate, map, dgpre,
-                                                                                        cnt, c, hw);
+    gate_bwd_reduce_kernel<4><<<dim3(cdiv(hw, 256), n), 256, 0, (hipStream_t)stream>>>(dout, a2, s, gate, dgpre, cnt,
+                                                                                        umax, c, hw);
   else
-    gate_bwd_reduce_kernel<1><<<dim3(cdiv(hw, 64), n), 256, 0, (hipStream_t)stream>>>(dout, a2, s, gate, map, dgpre,
-                                                                                       cnt, c, hw);
+    gate_bwd_reduce_kernel<1><<<dim3(cdiv(hw, 64), n), 256, 0, (hipStream_t)stream>>>(dout, a2, s, gate, dgpre, cnt,
+                                                                                       umax, c, hw);
   CM_CHECK_LAUNCH();
   return 0;
 }
@@ -667,7 +674,7 @@ int cm_conv7_bwd(const float* dgpre, const float* map, const float* w7, float* d
 }
 
 int cm_se_bwd_reduce(const float* dout, const float* a2, const float* s, const float* gate, const float* dmap,
-                     const float* map, const float* cnt, float* ds, int n, int c, int hw, const float* c7_partials,
+                     const float* umax, const float* cnt, float* ds, int n, int c, int hw, const float* c7_partials,
                      int c7_rows, float* dw7, cm_stream stream) {
   if (n <= 0 || c <= 0 || hw <= 0 || (c7_partials && (c7_rows <= 0 || !dw7))) return -22;
   const int cg = (c % 4 == 0 && (long long)n * c >= 4096) ? 4 : 1;   // channels per wave (needs enough waves)
@@ -677,16 +684,16 @@ int cm_se_bwd_reduce(const float* dout, const float* a2, const float* s, const f
     conv7_fold_split(c7_rows, &fb, &rpb);
     if ((unsigned)cdiv(c7_rows, rpb) > grid) return -22;
   }
-  const bool al = (((uintptr_t)dout | (uintptr_t)a2 | (uintptr_t)gate | (uintptr_t)dmap | (uintptr_t)map |
+  const bool al = (((uintptr_t)dout | (uintptr_t)a2 | (uintptr_t)gate | (uintptr_t)dmap | (uintptr_t)umax |
                     (uintptr_t)cnt) & 15) == 0;
 #define CM_SEBR(V)                                                                                               \
   do {                                                                                                           \
     if (cg == 4)                                                                                                 \
-      se_bwd_reduce_kernel<V, 4><<<grid, 256, 0, (hipStream_t)stream>>>(dout, a2, s, gate, dmap, map, cnt, ds,   \
+      se_bwd_reduce_kernel<V, 4><<<grid, 256, 0, (hipStream_t)stream>>>(dout, a2, s, gate, dmap, umax, cnt, ds,   \
                                                                         n * c, c, hw, c7_partials, c7_rows, rpb, \
                                                                         dw7);                                    \
     else                                                                                                         \
-      se_bwd_reduce_kernel<V, 1><<<grid, 256, 0, (hipStream_t)stream>>>(dout, a2, s, gate, dmap, map, cnt, ds,   \
+      se_bwd_reduce_kernel<V, 1><<<grid, 256, 0, (hipStream_t)stream>>>(dout, a2, s, gate, dmap, umax, cnt, ds,   \
                                                                         n * c, c, hw, c7_partials, c7_rows, rpb, \
                                                                         dw7);                                    \
   } while (0)

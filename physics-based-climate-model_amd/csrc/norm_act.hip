@@ -149,8 +149,8 @@ struct GateBwd {
   const float* dout;   // [N,C,HW]  gradient wrt the ConvBlock output
   const float* gate;   // [N,HW]    spatial gate (post-sigmoid)
   const float* dmap;   // [N,2,HW]  gradient wrt [mean_c U, max_c U]
-  const float* umax;   // [N,2,HW]  forward map (channel 1 = max_c U)
-  const float* cnt;    // [N,HW]    number of channels attaining the max
+  const float* umax;   // [N,HW]    max_c U as re-derived by gate_bwd_reduce (NOT the forward's stored map)
+  const float* cnt;    // [N,HW]    number of channels attaining umax (>= 1), same launch
   const float* s;      // [N,C]     SE scale
   const float* dpool;  // [N,C]     gradient wrt the SE squeeze (pooled mean)
   SeWgradArgs se;      // side duty: the SE weight gradients of the preceding cm_se_excite_bwd (se.dsig NULL: none)
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_kernel(const float* __
     const vec_t* gtc = MODE == 1 ? reinterpret_cast<const vec_t*>(gb.gate + (long long)n * HW) : nullptr;
     const vec_t* dac = MODE == 1 ? reinterpret_cast<const vec_t*>(gb.dmap + (long long)n * 2 * HW) : nullptr;
     const vec_t* dmc = MODE == 1 ? reinterpret_cast<const vec_t*>(gb.dmap + ((long long)n * 2 + 1) * HW) : nullptr;
-    const vec_t* mxc = MODE == 1 ? reinterpret_cast<const vec_t*>(gb.umax + ((long long)n * 2 + 1) * HW) : nullptr;
+    const vec_t* mxc = MODE == 1 ? reinterpret_cast<const vec_t*>(gb.umax + (long long)n * HW) : nullptr;
     const vec_t* ctc = MODE == 1 ? reinterpret_cast<const vec_t*>(gb.cnt + (long long)n * HW) : nullptr;
     const float sc = MODE == 1 ? gb.s[nc] : 0.f;
     const float dpl = MODE == 1 ? gb.dpool[nc] * inv_hw : 0.f;
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_reg_kernel(const float
       const float4 gtv = reinterpret_cast<const float4*>(gb.gate)[m0], ctv = reinterpret_cast<const float4*>(gb.cnt)[m0];
       const float4 dav = reinterpret_cast<const float4*>(gb.dmap)[2 * (long long)n * HWV + (ok ? i : 0)];
       const float4 dmv = reinterpret_cast<const float4*>(gb.dmap)[(2 * (long long)n + 1) * HWV + (ok ? i : 0)];
-      const float4 mxv = reinterpret_cast<const float4*>(gb.umax)[(2 * (long long)n + 1) * HWV + (ok ? i : 0)];
+      const float4 mxv = reinterpret_cast<const float4*>(gb.umax)[m0];
       const float sc = gb.s[nc], dpl = gb.dpool[nc] * inv_hw;
       auto one = [&](float a2e, float doe, float gte, float dae, float dme, float mxe, float cte) {
         const float U = a2e * sc;                      // bit-exact forward product: operand of the tie test
@@ -534,7 +534,7 @@ int cm_gn_silu_apply(const float* x, const float* gamma, const float* beta, cons
 }
 
 int cm_gn_silu_bwd_gated(const float* x, const float* gamma, const float* beta, const float* stats,
-                         const float* a2, const float* dout, const float* gate, const float* dmap, const float* fmap,
+                         const float* a2, const float* dout, const float* gate, const float* dmap, const float* umax,
                          const float* cnt, const float* s, const float* dpool, float* dx, float* dgamma,
                          float* dbeta, int n, int c, int hw, int groups, const float* se_dsig, const float* se_dz,
                          const float* se_z, const float* se_pooled, float* se_dw1, float* se_dw2, int se_cr,
@@ -542,7 +542,7 @@ int cm_gn_silu_bwd_gated(const float* x, const float* gamma, const float* beta, 
   if (n <= 0 || c <= 0 || hw <= 0 || groups <= 0 || c % groups) return -22;
   if (se_dsig && (!se_dz || !se_z || !se_pooled || !se_dw1 || !se_dw2 || se_cr <= 0)) return -22;
   GateBwd gb;
-  gb.a2 = a2; gb.dout = dout; gb.gate = gate; gb.dmap = dmap; gb.umax = fmap; gb.cnt = cnt; gb.s = s; gb.dpool = dpool;
+  gb.a2 = a2; gb.dout = dout; gb.gate = gate; gb.dmap = dmap; gb.umax = umax; gb.cnt = cnt; gb.s = s; gb.dpool = dpool;
   gb.se.dsig = se_dsig; gb.se.dz = se_dz; gb.se.z = se_z; gb.se.pooled = se_pooled; gb.se.dw1 = se_dw1; gb.se.dw2 = se_dw2;
   gb.se.N = n; gb.se.C = c; gb.se.Cr = se_cr;
   const bool vec = (hw % 4) == 0;

@@ -81,7 +81,7 @@ __global__ void scale_kernel(float* __restrict__ x, long long n, float s) {
 
 extern "C" {
 
-int cm_version(void) { return 2; }   // 2: bf16x6 + first-layer entry points, scratch/pooled/db parameters
+int cm_version(void) { return 3; }   // 3: gate backward derives (umax, cnt) itself; 2: bf16x6 + first-layer entry points
 const char* cm_arch(void) { return "gfx950"; }
 
 int cm_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,

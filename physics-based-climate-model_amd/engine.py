@@ -36,12 +36,13 @@ def _conv_jobs(p: Params, need_input_grad: bool):
             jobs.append((name + "/f", name, 0, w.shape[1], 0))
             if name != "enc1.body.0.weight" or need_input_grad:
                 jobs.append((name + "/d", name, 0, w.shape[1], 1))
-    wl = p["convlstm.cell.conv.weight"]
-    ch = wl.shape[0] // 4
-    cx = wl.shape[1] - ch
-    for key, off, cin, dg in (("lstm.x/f", 0, cx, 0), ("lstm.h/f", cx, ch, 0), ("lstm.x/d", 0, cx, 1),
-                              ("lstm.h/d", cx, ch, 1)):
-        jobs.append((key, "convlstm.cell.conv.weight", off, cin, dg))
+    wl = p.get("convlstm.cell.conv.weight")
+    if wl is not None:
+        ch = wl.shape[0] // 4
+        cx = wl.shape[1] - ch
+        for key, off, cin, dg in (("lstm.x/f", 0, cx, 0), ("lstm.h/f", cx, ch, 0), ("lstm.x/d", 0, cx, 1),
+                                  ("lstm.h/d", cx, ch, 1)):
+            jobs.append((key, "convlstm.cell.conv.weight", off, cin, dg))
     return jobs
 
 
@@ -72,7 +73,7 @@ class Plan:
 
     def __init__(self, p: Params, g: Optional[Params], need_input_grad: bool):
         from ._lib import lib
-        dev = p["head.weight"].device
+        dev = next(iter(p.values())).device
         self.key = self.signature(p, g, need_input_grad)
         jobs = _conv_jobs(p, need_input_grad)
         sizes = []
@@ -121,7 +122,8 @@ class Plan:
         self.gw: Dict[str, Tensor] = {}
         if g is not None:
             names = [n for n in p if n.endswith("body.0.weight") or n.endswith("body.3.weight")]
-            names.append("convlstm.cell.conv.weight")
+            if "convlstm.cell.conv.weight" in p:
+                names.append("convlstm.cell.conv.weight")
             total = sum(p[n].numel() for n in names)
             self.g_arena = torch.empty(total, device=dev, dtype=torch.float32)
             rec, o, blk = [], 0, 0
@@ -178,16 +180,26 @@ class Plan:
                                            torch.cuda.current_stream().cuda_stream), "unpack_batch")
 
 
-_PLANS: Dict[tuple, Plan] = {}
+_PLANS: "Dict[tuple, Plan]" = {}      # insertion order == recency (re-inserted on every hit)
+_PLANS_MAX = 8
 
 
 def get_plan(p: Params, g: Optional[Params] = None, need_input_grad: bool = False) -> Plan:
+    """Plan for this (parameter storage, gradient storage) pair.  The cache is a small LRU; a plan is evicted only
+    when nothing else holds it (``sys.getrefcount``): captured hipGraphs carry raw pointers into a plan's arenas and
+    tables, so ``HotPathTrainer`` keeps strong references to the plans its graphs were recorded with and those are
+    never dropped from under a replay (several models in one process, e.g. an ensemble, stay safe)."""
+    import sys
     key = Plan.signature(p, g, need_input_grad)
-    plan = _PLANS.get(key)
+    plan = _PLANS.pop(key, None)
     if plan is None:
-        if len(_PLANS) > 8:
-            _PLANS.clear()
-        plan = _PLANS[key] = Plan(p, g, need_input_grad)
+        plan = Plan(p, g, need_input_grad)
+        for k in list(_PLANS):
+            if len(_PLANS) < _PLANS_MAX:
+                break
+            if sys.getrefcount(_PLANS[k]) <= 2:      # the dict's reference + getrefcount's argument
+                del _PLANS[k]
+    _PLANS[key] = plan
     return plan
 
 
@@ -221,12 +233,12 @@ def _block_bwd(p: Params, pk, g: Params, gw: Params, ss: "_SideStream", prefix: 
     """Returns d(input) as one tensor [N, C0+C1, H, W] (or None); parameter gradients are accumulated into ``g``."""
     co = ctx.y1.shape[1]
     w1, w2, w7 = p[prefix + "se.fc.0.weight"], p[prefix + "se.fc.2.weight"], p[prefix + "spat.conv.weight"]
-    dmap, cnt, dpool, (dsig, dz) = ops.gates_bwd(dout, ctx.a2, ctx.s, ctx.z, ctx.pooled, ctx.gate, ctx.fmap, w1, w2, w7,
+    dmap, (umax, cnt), dpool, (dsig, dz) = ops.gates_bwd(dout, ctx.a2, ctx.s, ctx.z, ctx.pooled, ctx.gate, ctx.fmap, w1, w2, w7,
                                                  g[prefix + "se.fc.0.weight"], g[prefix + "se.fc.2.weight"],
                                                  g[prefix + "spat.conv.weight"], defer_se_wgrad=True)
     # (the SE weight gradients ride along with the GroupNorm backward launch)
     dy2 = ops.gn_silu_bwd_gated(ctx.y2, p[prefix + "body.4.weight"], p[prefix + "body.4.bias"], ctx.st2, ctx.a2, dout,
-                                ctx.gate, dmap, ctx.fmap, cnt, ctx.s, dpool, g[prefix + "body.4.weight"],
+                                ctx.gate, dmap, umax, cnt, ctx.s, dpool, g[prefix + "body.4.weight"],
                                 g[prefix + "body.4.bias"],
                                 se=(dsig, dz, ctx.z, ctx.pooled, g[prefix + "se.fc.0.weight"], g[prefix + "se.fc.2.weight"]))
     ss.run(lambda: ops.wgrad3x3(ctx.a1, dy2, gw[prefix + "body.3.weight"]), ctx.a1, dy2)
@@ -337,9 +349,99 @@ class _Deferred:
         self.keep.clear()
 
 
+class _LstmCtx:
+    """What the ConvLSTM backward needs from its forward."""
+    __slots__ = ("B", "T", "s4", "gx", "hprev", "call", "bott")
+
+
+def convlstm_fwd(p: Params, pk, s4: Tensor, B: int, T: int, save: bool = True):
+    """ConvLSTM.forward (reference src/convlstm.py:27-35) on the folded encoder output s4 [B*T, Cx, h, w]
+    (sample n = b*T + t).  Returns (h_last [B, Ch, h, w], ctx); ctx.hprev[:, t] = h_{t-1} (slot 0 = 0), so the hidden
+    state of step t < T-1 is ctx.hprev[:, t+1] and the last one is h_last."""
+    wl, bl = p["convlstm.cell.conv.weight"], p["convlstm.cell.conv.bias"]
+    ch = wl.shape[0] // 4
+    h8, w8 = s4.shape[2], s4.shape[3]
+    dev = s4.device
+    gx = pk.conv("lstm.x/f", s4, 4 * ch, bias=bl).view(B, T, 4 * ch, h8, w8)
+    hprev = _zeros(B, T, ch, h8, w8, device=dev)             # hprev[:, t] = h_{t-1}; slot 0 stays 0
+    call = torch.empty(B, T, ch, h8, w8, device=dev, dtype=torch.float32)
+    bott = torch.empty(B, ch, h8, w8, device=dev, dtype=torch.float32)
+    for t in range(T):
+        if t > 0:
+            pk.conv("lstm.h/f", hprev[:, t], 4 * ch, resid=gx[:, t], out=gx[:, t])
+        ops.lstm_gates_fwd(gx[:, t], call[:, t - 1] if t > 0 else None, call[:, t],
+                           hprev[:, t + 1] if t + 1 < T else bott)
+    ctx = None
+    if save:
+        ctx = _LstmCtx()
+        ctx.B, ctx.T, ctx.s4, ctx.gx, ctx.hprev, ctx.call, ctx.bott = B, T, s4, gx, hprev, call, bott
+    return bott, ctx
+
+
+def convlstm_bwd(p: Params, pk, g: Params, gw: Params, ss, ctx: _LstmCtx, dbott: Optional[Tensor],
+                 dh_all_steps: Optional[Tensor] = None, before_chain=None):
+    """BPTT through the ConvLSTM.  ``dbott``: gradient wrt the last hidden state (the only one the model consumes,
+    src/unet_convlstm_attention.py:88); ``dh_all_steps`` [B, T, Ch, h, w] (optional) adds an external gradient to every
+    step's hidden state (generic ConvLSTM use; parity fixture convlstm_alldy.npz).  Accumulates the cell's weight /
+    bias gradients and returns d(s4) [B*T, Cx, h, w].  ``before_chain`` (optional callable) is issued right before the
+    serial chain starts (work for a side stream)."""
+    B, T = ctx.B, ctx.T
+    gx, hprev, call = ctx.gx, ctx.hprev, ctx.call
+    ch = hprev.shape[2]
+    cx = ctx.s4.shape[1]
+    h8, w8 = hprev.shape[3], hprev.shape[4]
+    dev = gx.device
+    dc = torch.empty(B, ch, h8, w8, device=dev, dtype=torch.float32)
+    dhrec = None
+    # the recurrent data gradients are tiny K-split launches: one zero fill for all T-1 outputs instead of one each
+    dh_rec_all = _zeros(max(T - 1, 1), B, ch, h8, w8, device=dev)
+    if before_chain is not None:
+        before_chain()
+    for t in range(T - 1, -1, -1):
+        ext = None
+        if dh_all_steps is not None:
+            ext = dh_all_steps[:, t]
+        if t == T - 1 and dbott is not None:
+            if ext is None:
+                ext = dbott
+            else:
+                ext = ext + dbott          # (test-only combination; the model passes dbott alone)
+        # dh_t = external part + recurrent part (either may be absent); dc carries dL/dc_t
+        ops.lstm_gates_bwd(gx[:, t], call[:, t - 1] if t > 0 else None, call[:, t], ext, dhrec, dc, first=(t == T - 1))
+        if t > 0:
+            dhrec = pk.conv("lstm.h/d", gx[:, t], ch, out=dh_rec_all[t - 1], out_zeroed=True)
+    dA = gx.view(B * T, 4 * ch, h8, w8)            # now holds d(pre-activations) for every (b, t)
+    gl = gw["convlstm.cell.conv.weight"]
+
+    def lstm_wgrads():
+        ops.wgrad3x3(ctx.s4, dA, gl, c_off=0)
+        if T > 1:
+            ops.wgrad3x3(hprev.view(B * T, ch, h8, w8), dA, gl, c_off=cx)   # hprev[:, 0] == 0 contributes nothing
+    ss.run(lstm_wgrads, ctx.s4, dA, hprev)
+    ops.channel_sum(dA, g["convlstm.cell.conv.bias"])
+    return pk.conv("lstm.x/d", dA, cx)
+
+
+def up_fwd(p: Params, pk, prefix: str, x: Tensor, skip: Tensor, save: bool = True):
+    """Up.forward (reference src/unet.py:66-69): ConvTranspose2d(2, s2) -> cat([up, skip]) -> ConvBlock; the concat is
+    virtual.  Returns (out, (block ctx, x))."""
+    u = ops.convT2x2_fwd(x, p[prefix + "up.weight"], p[prefix + "up.bias"])
+    out, ctx = _block_fwd(p, pk, prefix + "conv.", u, skip, save)
+    return out, (ctx, x)
+
+
+def up_bwd(p: Params, pk, g: Params, gw: Params, ss, prefix: str, saved, dout: Tensor):
+    """Returns (d(x), d(cat)) -- d(skip) is d(cat)[:, c_up:], consumed in place by the caller."""
+    ctx, x = saved
+    dcat = _block_bwd(p, pk, g, gw, ss, prefix + "conv.", ctx, dout)
+    b = ctx.x0.shape[1]
+    dx = ops.convT2x2_bwd(x, p[prefix + "up.weight"], dcat[:, :b], g[prefix + "up.weight"], g[prefix + "up.bias"])
+    return dx, dcat
+
+
 class Saved:
     """Everything the backward needs from one forward."""
-    __slots__ = ("B", "T", "enc", "pools_in", "s4", "gx", "hprev", "call", "bott", "ups", "up_in", "d1", "x_shape")
+    __slots__ = ("B", "T", "enc", "lstm", "ups", "d1", "x_shape")
 
 
 def forward(p: Params, pk, x_seq: Tensor, save: bool = True, head: bool = True):
@@ -364,40 +466,25 @@ def forward(p: Params, pk, x_seq: Tensor, save: bool = True, head: bool = True):
     s3, c3, p3 = _block_fwd(p, pk, "enc3.conv.", p2, None, save, pool=True)
     s4, c4 = _block_fwd(p, pk, "enc4.conv.", p3, None, save)
 
-    # ---- ConvLSTM bottleneck ---------------------------------------------------------------------------
-    wl, bl = p["convlstm.cell.conv.weight"], p["convlstm.cell.conv.bias"]
-    ch = wl.shape[0] // 4
-    h8, w8 = H // 8, W // 8
-    gx = pk.conv("lstm.x/f", s4, 4 * ch, bias=bl).view(B, T, 4 * ch, h8, w8)
-    hprev = _zeros(B, T, ch, h8, w8, device=x.device)       # hprev[:, t] = h_{t-1}; slot 0 stays 0
-    call = torch.empty(B, T, ch, h8, w8, device=x.device, dtype=torch.float32)
-    bott = torch.empty(B, ch, h8, w8, device=x.device, dtype=torch.float32)
+    # ---- time-mean skips (beside the recurrence when the side stream is on) + ConvLSTM bottleneck --------
     skips = []
     side = _SideStream(x.device, OVERLAP_LSTM)
-    side.run(lambda: skips.extend(ops.time_mean(sk, B, T) for sk in (s1, s2, s3)), s1, s2, s3)   # beside the recurrence
-    for t in range(T):
-        if t > 0:
-            pk.conv("lstm.h/f", hprev[:, t], 4 * ch, resid=gx[:, t], out=gx[:, t])
-        ops.lstm_gates_fwd(gx[:, t], call[:, t - 1] if t > 0 else None, call[:, t],
-                           hprev[:, t + 1] if t + 1 < T else bott)
-
-    # ---- time-mean skips + decoder ---------------------------------------------------------------------
+    side.run(lambda: skips.extend(ops.time_mean(sk, B, T) for sk in (s1, s2, s3)), s1, s2, s3)
+    bott, lctx = convlstm_fwd(p, pk, s4, B, T, save)
     side.join()
     k1, k2, k3 = skips
-    u3 = ops.convT2x2_fwd(bott, p["up3.up.weight"], p["up3.up.bias"])
-    d3, cu3 = _block_fwd(p, pk, "up3.conv.", u3, k3, save)
-    u2 = ops.convT2x2_fwd(d3, p["up2.up.weight"], p["up2.up.bias"])
-    d2, cu2 = _block_fwd(p, pk, "up2.conv.", u2, k2, save)
-    u1 = ops.convT2x2_fwd(d2, p["up1.up.weight"], p["up1.up.bias"])
-    d1, cu1 = _block_fwd(p, pk, "up1.conv.", u1, k1, save)
+
+    # ---- decoder ---------------------------------------------------------------------------------------
+    d3, u3 = up_fwd(p, pk, "up3.", bott, k3, save)
+    d2, u2 = up_fwd(p, pk, "up2.", d3, k2, save)
+    d1, u1 = up_fwd(p, pk, "up1.", d2, k1, save)
     pred = ops.head_fwd(d1, p["head.weight"], p["head.bias"]) if head else None
 
     if save:
         sv.B, sv.T, sv.x_shape = B, T, tuple(x_seq.shape)
         sv.enc = (c1, c2, c3, c4)
-        sv.s4, sv.gx, sv.hprev, sv.call, sv.bott = s4, gx, hprev, call, bott
-        sv.ups = (cu3, cu2, cu1)
-        sv.up_in = (bott, d3, d2)
+        sv.lstm = lctx
+        sv.ups = (u3, u2, u1)
         sv.d1 = d1
     return pred, sv
 
@@ -413,52 +500,24 @@ def backward(p: Params, pk, g: Params, sv: Saved, dpred: Optional[Tensor], need_
     plan.zero_staging()
     dev = (dpred if dpred is not None else dd1).device
     ss = _SideStream(dev, OVERLAP_WGRAD)
-    B, T = sv.B, sv.T
+    T = sv.T
     c1, c2, c3, c4 = sv.enc
-    cu3, cu2, cu1 = sv.ups
-    bott, d3, d2 = sv.up_in
+    u3, u2, u1 = sv.ups
 
     # ---- head + decoder --------------------------------------------------------------------------------
     if dd1 is None:
         dd1 = ops.head_bwd(dpred, sv.d1, p["head.weight"], g["head.weight"], g["head.bias"])
     dec = _Deferred(OVERLAP_LSTM and not OVERLAP_WGRAD)      # decoder weight gradients: issued beside the LSTM chain
     dss = dec if dec.enabled else ss
-    dcat1 = _block_bwd(p, pk, g, gw, dss, "up1.conv.", cu1, dd1)
-    b1 = cu1.x0.shape[1]
-    dd2 = ops.convT2x2_bwd(d2, p["up1.up.weight"], dcat1[:, :b1], g["up1.up.weight"], g["up1.up.bias"])
-    dcat2 = _block_bwd(p, pk, g, gw, dss, "up2.conv.", cu2, dd2)
-    b2 = cu2.x0.shape[1]
-    dd3 = ops.convT2x2_bwd(d3, p["up2.up.weight"], dcat2[:, :b2], g["up2.up.weight"], g["up2.up.bias"])
-    dcat3 = _block_bwd(p, pk, g, gw, dss, "up3.conv.", cu3, dd3)
-    b3 = cu3.x0.shape[1]
-    dbott = ops.convT2x2_bwd(bott, p["up3.up.weight"], dcat3[:, :b3], g["up3.up.weight"], g["up3.up.bias"])
+    dd2, dcat1 = up_bwd(p, pk, g, gw, dss, "up1.", u1, dd1)
+    dd3, dcat2 = up_bwd(p, pk, g, gw, dss, "up2.", u2, dd2)
+    dbott, dcat3 = up_bwd(p, pk, g, gw, dss, "up3.", u3, dd3)
+    b1, b2, b3 = u1[0].x0.shape[1], u2[0].x0.shape[1], u3[0].x0.shape[1]
 
     # ---- ConvLSTM, back through time -------------------------------------------------------------------
-    gx, hprev, call = sv.gx, sv.hprev, sv.call
-    ch = hprev.shape[2]
-    cx = sv.s4.shape[1]
-    h8, w8 = hprev.shape[3], hprev.shape[4]
-    dc = torch.empty(B, ch, h8, w8, device=dev, dtype=torch.float32)
-    dhrec = None
-    # the recurrent data gradients are tiny K-split launches: one zero fill for all T-1 outputs instead of one each
-    dh_all = _zeros(max(T - 1, 1), B, ch, h8, w8, device=dev)
     side = _SideStream(dev, dec.enabled)
-    side.run(dec.flush, *list(dec.keep))      # (the side stream keeps the operands alive until its join)
-    for t in range(T - 1, -1, -1):
-        ops.lstm_gates_bwd(gx[:, t], call[:, t - 1] if t > 0 else None, call[:, t], dbott if t == T - 1 else None,
-                           dhrec, dc, first=(t == T - 1))
-        if t > 0:
-            dhrec = pk.conv("lstm.h/d", gx[:, t], ch, out=dh_all[t - 1], out_zeroed=True)
-    dA = gx.view(B * T, 4 * ch, h8, w8)            # now holds d(pre-activations) for every (b, t)
-    gl = gw["convlstm.cell.conv.weight"]
-
-    def lstm_wgrads():
-        ops.wgrad3x3(sv.s4, dA, gl, c_off=0)
-        if T > 1:
-            ops.wgrad3x3(hprev.view(B * T, ch, h8, w8), dA, gl, c_off=cx)   # hprev[:, 0] == 0 contributes nothing
-    ss.run(lstm_wgrads, sv.s4, dA, hprev)
-    ops.channel_sum(dA, g["convlstm.cell.conv.bias"])
-    ds4 = pk.conv("lstm.x/d", dA, cx)
+    ds4 = convlstm_bwd(p, pk, g, gw, ss, sv.lstm, dbott,
+                       before_chain=lambda: side.run(dec.flush, *list(dec.keep)))   # (kept alive until the join)
 
     # ---- encoder ---------------------------------------------------------------------------------------
     dp3 = _block_bwd(p, pk, g, gw, ss, "enc4.conv.", c4, ds4)
@@ -470,5 +529,68 @@ def backward(p: Params, pk, g: Params, sv: Saved, dpred: Optional[Tensor], need_
     dx = _block_bwd(p, pk, g, gw, ss, "enc1.", c1, ds1, need_dx=need_dx)
     ss.join()
     side.join()
+    plan.unpack()
+    return dx.view(sv.x_shape) if dx is not None else None
+
+
+# ------------------------------------------------------------------------------------------------- plain UNet
+class SavedUNet:
+    """What the backward of the single-frame UNet needs."""
+    __slots__ = ("enc", "bott", "ups", "d1", "x_shape")
+
+
+def unet_forward(p: Params, pk, x: Tensor, save: bool = True, head: bool = True):
+    """UNet.forward (reference src/unet.py:99-109): x [B,C,H,W] -> [B,out_ch,H,W].  Same blocks as the hot-path model
+    (ConvBlock / Down / Up, src/unet.py:32-69) without the frame loop and the ConvLSTM: a ConvBlock bottleneck at H/8
+    and direct (not time-averaged) skips."""
+    if x.dim() != 4:
+        raise RuntimeError("expected x of shape [B, C, H, W]")
+    B, C, H, W = x.shape
+    if C != p["enc1.body.0.weight"].shape[1]:
+        raise RuntimeError(f"channel mismatch: input has {C} channels, enc1 expects "
+                           f"{p['enc1.body.0.weight'].shape[1]}")
+    if H % 8 or W % 8:
+        raise RuntimeError("H and W must be divisible by 8 (three 2x2 poolings)")
+    x = x.contiguous()
+    s1, c1, p1 = _block_fwd(p, pk, "enc1.", x, None, save, pool=True)
+    s2, c2, p2 = _block_fwd(p, pk, "enc2.conv.", p1, None, save, pool=True)
+    s3, c3, p3 = _block_fwd(p, pk, "enc3.conv.", p2, None, save, pool=True)
+    s4, c4 = _block_fwd(p, pk, "enc4.conv.", p3, None, save)
+    bt, cb = _block_fwd(p, pk, "bott.", s4, None, save)
+    d3, u3 = up_fwd(p, pk, "up3.", bt, s3, save)
+    d2, u2 = up_fwd(p, pk, "up2.", d3, s2, save)
+    d1, u1 = up_fwd(p, pk, "up1.", d2, s1, save)
+    pred = ops.head_fwd(d1, p["head.weight"], p["head.bias"]) if head else None
+    sv = None
+    if save:
+        sv = SavedUNet()
+        sv.enc, sv.bott, sv.ups, sv.d1, sv.x_shape = (c1, c2, c3, c4), cb, (u3, u2, u1), d1, tuple(x.shape)
+    return pred, sv
+
+
+def unet_backward(p: Params, pk, g: Params, sv: SavedUNet, dpred: Optional[Tensor], need_dx: bool = False,
+                  dd1: Optional[Tensor] = None):
+    plan = get_plan(p, g, need_dx)
+    gw = plan.gw
+    plan.zero_staging()
+    dev = (dpred if dpred is not None else dd1).device
+    ss = _SideStream(dev, OVERLAP_WGRAD)
+    c1, c2, c3, c4 = sv.enc
+    u3, u2, u1 = sv.ups
+    if dd1 is None:
+        dd1 = ops.head_bwd(dpred, sv.d1, p["head.weight"], g["head.weight"], g["head.bias"])
+    dd2, dcat1 = up_bwd(p, pk, g, gw, ss, "up1.", u1, dd1)
+    dd3, dcat2 = up_bwd(p, pk, g, gw, ss, "up2.", u2, dd2)
+    dbt, dcat3 = up_bwd(p, pk, g, gw, ss, "up3.", u3, dd3)
+    b1, b2, b3 = u1[0].x0.shape[1], u2[0].x0.shape[1], u3[0].x0.shape[1]
+    ds4 = _block_bwd(p, pk, g, gw, ss, "bott.", sv.bott, dbt)
+    dp3 = _block_bwd(p, pk, g, gw, ss, "enc4.conv.", c4, ds4)
+    ds3 = ops.maxpool2_bwd(c3.out, dp3, dcat3[:, b3:], t=1)       # pooling backward + the skip's own gradient
+    dp2 = _block_bwd(p, pk, g, gw, ss, "enc3.conv.", c3, ds3)
+    ds2 = ops.maxpool2_bwd(c2.out, dp2, dcat2[:, b2:], t=1)
+    dp1 = _block_bwd(p, pk, g, gw, ss, "enc2.conv.", c2, ds2)
+    ds1 = ops.maxpool2_bwd(c1.out, dp1, dcat1[:, b1:], t=1)
+    dx = _block_bwd(p, pk, g, gw, ss, "enc1.", c1, ds1, need_dx=need_dx)
+    ss.join()
     plan.unpack()
     return dx.view(sv.x_shape) if dx is not None else None

@@ -1,14 +1,18 @@
-"""Drop-in ``AttUNetConvLSTM`` and ``get_model`` for the reference's model seam, running on hand-written HIP kernels.
+"""Drop-in model classes and ``get_model`` for the reference's model seam, running on hand-written HIP kernels.
 
 Mirrors (names, argument meaning, state_dict layout, error behaviour):
-  * ``AttUNetConvLSTM(in_ch, out_ch, base, seq_len)``  -- reference src/unet_convlstm_attention.py:27-104
-  * ``get_model(cfg)``                                 -- reference src/models.py:7-38
+  * ``AttUNetConvLSTM(in_ch, out_ch, base, seq_len)``  -- reference src/unet_convlstm_attention.py:27-104 (the hot path)
+  * ``UNet(in_ch, out_ch, base)``                      -- reference src/unet.py:72-109 (same blocks, single frame)
+  * ``get_model(cfg)``                                 -- reference src/models.py:7-38 (all four ``model.type`` values)
 
-The module owns exactly the reference's 75 parameters (same names / shapes / registration order, so checkpoints load
+A HIP module owns exactly the reference's parameters (same names / shapes / registration order, so checkpoints load
 both ways, and the same default initialisation under ``torch.manual_seed``): they live in stock ``nn.Conv2d`` /
 ``nn.GroupNorm`` / ``nn.ConvTranspose2d`` *containers* that are never called.  ``forward`` hands the parameter
-tensors to ``engine.forward`` (HIP kernels) through one ``autograd.Function`` so that the harness's
-``loss.backward()`` works unchanged.  There is no CPU path: a CPU input raises ``RuntimeError``.
+tensors to the engine (HIP kernels) through one ``autograd.Function`` so that the harness's ``loss.backward()``
+works unchanged.  There is no CPU path for these classes: a CPU input raises ``RuntimeError``.
+
+``SimpleCNN`` (BASELINE.json configs[0], "CPU plumbing, no GPU") and -- until its HIP path lands -- nothing else are
+stock-torch modules from ``host_models.py``.
 """
 from typing import Dict, List
 
@@ -55,60 +59,47 @@ def _up_block(ci: int, cskip: int, co: int) -> _Holder:
 
 
 class _HotPathFunction(torch.autograd.Function):
-    """forward/backward of the whole model as one autograd node (inputs: x_seq + the parameters with gradients)."""
+    """forward/backward of a whole model as one autograd node (inputs: x + the parameters with gradients)."""
 
     @staticmethod
-    def forward(ctx, module, x_seq, *tensors):
+    def forward(ctx, module, x, *tensors):
         names = module._grad_names
         p = module._param_dict()
         # (grad mode is always off inside Function.forward: decide from what autograd says it will ask for)
         need_x = bool(ctx.needs_input_grad[1])
         save = any(ctx.needs_input_grad)
         pk = engine.get_plan(p, None, need_x).pack()
-        pred, sv = engine.forward(p, pk, x_seq, save=save)
+        pred, sv = module._engine_forward(p, pk, x, save=save)
         ctx.module, ctx.sv, ctx.pk, ctx.p, ctx.need_x, ctx.names = module, sv, pk, p, need_x, names
         return pred
 
     @staticmethod
     def backward(ctx, dpred):
         m = ctx.module
+        if ctx.sv is None:
+            raise RuntimeError("backward through this forward was already run (its saved activations are freed)")
         flat = m._grad_workspace(dpred.device)
         engine._zero_(flat)
         g = m._views(flat)
-        dx = engine.backward(ctx.p, ctx.pk, g, ctx.sv, dpred.contiguous(), need_dx=ctx.need_x)
+        dx = m._engine_backward(ctx.p, ctx.pk, g, ctx.sv, dpred.contiguous(), need_dx=ctx.need_x)
         ctx.sv = None
-        return (None, dx) + tuple(g[n] for n in ctx.names)
+        # Autograd may ADOPT what is returned here as p.grad (AccumulateGrad steals a contiguous gradient), so it must
+        # not alias the persistent workspace the next backward zeroes and rewrites: hand out views of a fresh flat copy
+        # (one 4*P-byte device copy).  Gradient accumulation over micro-batches, zero_grad(set_to_none=False) and
+        # several model calls in one autograd graph all depend on this.
+        out = m._views(flat.clone())
+        return (None, dx) + tuple(out[n] for n in ctx.names)
 
 
-class AttUNetConvLSTM(nn.Module):
-    """Per-frame attention-UNet encoder, ConvLSTM bottleneck over T, time-mean skips, UNet decoder, 1x1 head.
+class _HipModule(nn.Module):
+    """Shared machinery of the HIP-backed models: flat parameter / gradient buffers and the autograd bridge."""
 
-    x_seq [B, T, in_ch, H, W] (H, W divisible by 8) -> [B, out_ch, H, W].  ``seq_len`` is accepted and, as in the
-    reference, not enforced: T is taken from the input.
-    """
+    _INPUT_DIMS = 4
+    _NO_GRAD_PREFIXES = ()            # parameters the forward never uses (grad stays None, as in the reference)
 
-    def __init__(self, in_ch: int = 5, out_ch: int = 2, base: int = 16, seq_len: int = 3):
-        super().__init__()
-        if base % 8:
-            raise ValueError("base must be a multiple of 8 (GroupNorm(8, base), SE ratio 8)")
-        self.seq_len = seq_len
-        self.in_ch, self.out_ch, self.base = in_ch, out_ch, base
-        b = base
-        # registration order == reference __init__ (src/unet_convlstm_attention.py:33-56)
-        self.enc1 = _gated_block(in_ch, b)
-        self.enc2 = _pooled_block(b, 2 * b)
-        self.enc3 = _pooled_block(2 * b, 4 * b)
-        self.enc4 = _pooled_block(4 * b, 8 * b)
-        self.convlstm = _Holder()
-        self.convlstm.cell = _Holder()
-        self.convlstm.cell.conv = nn.Conv2d(8 * b + 4 * b, 4 * 4 * b, 3, padding=1)
-        # defined-but-unused in the reference (src/unet_convlstm_attention.py:46-49); kept for state_dict parity
-        self.post_conv = nn.Sequential(nn.Conv2d(4 * b, 4 * b, kernel_size=3, padding=1), nn.ReLU())
-        self.up3 = _up_block(4 * b, 4 * b, 4 * b)
-        self.up2 = _up_block(4 * b, 2 * b, 2 * b)
-        self.up1 = _up_block(2 * b, b, b)
-        self.head = nn.Conv2d(b, out_ch, kernel_size=1)
-        self._grad_names: List[str] = [n for n, _ in self.named_parameters() if not n.startswith("post_conv.")]
+    def _finish_init(self):
+        self._grad_names: List[str] = [n for n, _ in self.named_parameters()
+                                       if not n.startswith(self._NO_GRAD_PREFIXES or ("\0",))]
         self._flat = None          # flat parameter buffer once flatten_parameters_() ran
         self._flat_g = None
         self._layout = None
@@ -118,7 +109,7 @@ class AttUNetConvLSTM(nn.Module):
         if self._layout is None:
             off, lay = 0, {}
             named = dict(self.named_parameters())
-            order = self._grad_names + [n for n in named if n.startswith("post_conv.")]
+            order = self._grad_names + [n for n in named if n not in set(self._grad_names)]
             for n in order:
                 k = named[n].numel()
                 lay[n] = (off, k, tuple(named[n].shape))
@@ -131,7 +122,7 @@ class AttUNetConvLSTM(nn.Module):
 
     @property
     def n_flat_trainable(self) -> int:
-        """Length (floats, padded) of the flat prefix that carries gradients (everything but post_conv.*)."""
+        """Length (floats, padded) of the flat prefix that carries gradients."""
         self._build_layout()
         return self._n_trainable
 
@@ -171,23 +162,89 @@ class AttUNetConvLSTM(nn.Module):
         return {n: t for n, t in self.named_parameters()}
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x_seq: torch.Tensor) -> torch.Tensor:
-        if not x_seq.is_cuda:
-            raise RuntimeError("AttUNetConvLSTM (climate_amd) runs on the MI355X HIP path only; got a CPU tensor. "
-                               "The CPU restatement lives in oracle/ and is test infrastructure.")
-        if x_seq.dtype != torch.float32:
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda:
+            raise RuntimeError(f"{type(self).__name__} (climate_amd) runs on the MI355X HIP path only; got a CPU "
+                               "tensor.  The CPU restatement lives in oracle/ and is test infrastructure.")
+        if x.dtype != torch.float32:
             raise RuntimeError("expected float32 input (trainer.precision: 32)")
         named = dict(self.named_parameters())
         tensors = [named[n] for n in self._grad_names]
         if any(not t.is_cuda for t in tensors):
             raise RuntimeError("module parameters are on the CPU; call .cuda() first")
-        return _HotPathFunction.apply(self, x_seq, *tensors)
+        return _HotPathFunction.apply(self, x, *tensors)
+
+
+class AttUNetConvLSTM(_HipModule):
+    """Per-frame attention-UNet encoder, ConvLSTM bottleneck over T, time-mean skips, UNet decoder, 1x1 head.
+
+    x_seq [B, T, in_ch, H, W] (H, W divisible by 8) -> [B, out_ch, H, W].  ``seq_len`` is accepted and, as in the
+    reference, not enforced: T is taken from the input.
+    """
+
+    _INPUT_DIMS = 5
+    _NO_GRAD_PREFIXES = ("post_conv.",)
+
+    def __init__(self, in_ch: int = 5, out_ch: int = 2, base: int = 16, seq_len: int = 3):
+        super().__init__()
+        if base % 8:
+            raise ValueError("base must be a multiple of 8 (GroupNorm(8, base), SE ratio 8)")
+        self.seq_len = seq_len
+        self.in_ch, self.out_ch, self.base = in_ch, out_ch, base
+        b = base
+        # registration order == reference __init__ (src/unet_convlstm_attention.py:33-56)
+        self.enc1 = _gated_block(in_ch, b)
+        self.enc2 = _pooled_block(b, 2 * b)
+        self.enc3 = _pooled_block(2 * b, 4 * b)
+        self.enc4 = _pooled_block(4 * b, 8 * b)
+        self.convlstm = _Holder()
+        self.convlstm.cell = _Holder()
+        self.convlstm.cell.conv = nn.Conv2d(8 * b + 4 * b, 4 * 4 * b, 3, padding=1)
+        # defined-but-unused in the reference (src/unet_convlstm_attention.py:46-49); kept for state_dict parity
+        self.post_conv = nn.Sequential(nn.Conv2d(4 * b, 4 * b, kernel_size=3, padding=1), nn.ReLU())
+        self.up3 = _up_block(4 * b, 4 * b, 4 * b)
+        self.up2 = _up_block(4 * b, 2 * b, 2 * b)
+        self.up1 = _up_block(2 * b, b, b)
+        self.head = nn.Conv2d(b, out_ch, kernel_size=1)
+        self._finish_init()
+
+    def _engine_forward(self, p, pk, x, save=True, head=True):
+        return engine.forward(p, pk, x, save=save, head=head)
+
+    def _engine_backward(self, p, pk, g, sv, dpred, need_dx=False, dd1=None):
+        return engine.backward(p, pk, g, sv, dpred, need_dx=need_dx, dd1=dd1)
+
+
+class UNet(_HipModule):
+    """Depth-4 attention UNet on one frame (reference src/unet.py:72-109): x [B, in_ch, H, W] -> [B, out_ch, H, W].
+    Same HIP kernels as the hot-path model; 82 parameters (enc1-4, bott, up3-1, head), all trained."""
+
+    def __init__(self, in_ch: int = 5, out_ch: int = 2, base: int = 16):
+        super().__init__()
+        if base % 8:
+            raise ValueError("base must be a multiple of 8 (GroupNorm(8, base), SE ratio 8)")
+        self.in_ch, self.out_ch, self.base = in_ch, out_ch, base
+        b = base
+        # registration order == reference __init__ (src/unet.py:81-97); Down = MaxPool2d + ConvBlock under `.conv`
+        self.enc1 = _gated_block(in_ch, b)
+        self.enc2 = _pooled_block(b, 2 * b)
+        self.enc3 = _pooled_block(2 * b, 4 * b)
+        self.enc4 = _pooled_block(4 * b, 8 * b)
+        self.bott = _gated_block(8 * b, 8 * b)
+        self.up3 = _up_block(8 * b, 4 * b, 4 * b)
+        self.up2 = _up_block(4 * b, 2 * b, 2 * b)
+        self.up1 = _up_block(2 * b, b, b)
+        self.head = nn.Conv2d(b, out_ch, kernel_size=1)
+        self._finish_init()
+
+    def _engine_forward(self, p, pk, x, save=True, head=True):
+        return engine.unet_forward(p, pk, x, save=save, head=head)
+
+    def _engine_backward(self, p, pk, g, sv, dpred, need_dx=False, dd1=None):
+        return engine.unet_backward(p, pk, g, sv, dpred, need_dx=need_dx, dd1=dd1)
 
 
 # ---------------------------------------------------------------------------------------------------- factory
-_OUT_OF_SCOPE = ("SimpleCNN", "cnn_transformer", "unet")
-
-
 def _get(cfg, key, default=None):
     try:
         v = cfg[key] if not hasattr(cfg, key) else getattr(cfg, key)
@@ -196,21 +253,38 @@ def _get(cfg, key, default=None):
     return default if v is None else v
 
 
-def get_model(cfg):
-    """Model factory keyed on ``cfg.model.type`` (reference src/models.py:7-38).
+def _items(node):
+    return node.items() if hasattr(node, "items") else vars(node).items()
 
-    Differences from the reference, both deliberate: ``in_ch`` is ``cfg.model.in_ch`` when present,
-    else ``len(cfg.data.input_vars)`` (the reference hard-codes 7, which cannot run with its own 5-variable data
-    config); ``cfg.model.seq_len`` / ``cfg.data.seq_len`` is forwarded when present.
+
+def get_model(cfg):
+    """Model factory keyed on ``cfg.model.type`` (reference src/models.py:7-38); every type the reference knows is
+    served, unknown ones raise the reference's ``ValueError``.
+
+      * ``unet_convlstm_attention`` -> AttUNetConvLSTM on the HIP engine (the hot path);
+      * ``unet``                    -> UNet on the HIP engine (same kernels, single frame);
+      * ``cnn_transformer``         -> CNNTransformer (``cnn_transformer.py``: HIP attention path);
+      * ``SimpleCNN``               -> the stock-torch SimpleCNN (BASELINE configs[0]: "CPU PyTorch, plumbing").
+
+    Differences from the reference, both deliberate: for ``unet_convlstm_attention`` ``in_ch`` is
+    ``cfg.model.in_ch`` when present, else ``len(cfg.data.input_vars)`` (the reference hard-codes 7, which cannot run
+    with its own 5-variable data config); ``cfg.model.seq_len`` / ``cfg.data.seq_len`` is forwarded when present.
     """
     mtype = cfg.model.type
+    n_in, n_out = len(cfg.data.input_vars), len(cfg.data.output_vars)
     if mtype == "unet_convlstm_attention":
-        in_ch = _get(cfg.model, "in_ch", None) or len(cfg.data.input_vars)
+        in_ch = _get(cfg.model, "in_ch", None) or n_in
         seq_len = _get(cfg.model, "seq_len", None) or _get(cfg.data, "seq_len", 3)
-        return AttUNetConvLSTM(in_ch=int(in_ch), out_ch=len(cfg.data.output_vars),
-                               base=int(cfg.model.base_channels), seq_len=int(seq_len))
-    if mtype in _OUT_OF_SCOPE:
-        raise NotImplementedError(
-            f"model type {mtype!r} is outside this package's hot-path scope (see DESIGN.md); "
-            "only 'unet_convlstm_attention' has an MI355X-native implementation")
+        return AttUNetConvLSTM(in_ch=int(in_ch), out_ch=n_out, base=int(cfg.model.base_channels), seq_len=int(seq_len))
+    if mtype == "unet":
+        return UNet(in_ch=n_in, out_ch=n_out, base=int(cfg.model.base_channels))
+    if mtype == "SimpleCNN":
+        from .host_models import SimpleCNN
+        kwargs = {k: v for k, v in _items(cfg.model) if k != "type"}      # src/models.py:9-13
+        return SimpleCNN(n_input_channels=n_in, n_output_channels=n_out, **kwargs)
+    if mtype == "cnn_transformer":
+        from .cnn_transformer import CNNTransformer
+        return CNNTransformer(in_channels=n_in, out_channels=n_out, embed_dim=int(cfg.model.embed_dim),
+                              depth=int(cfg.model.depth), n_heads=int(cfg.model.n_heads),
+                              mlp_dim=int(cfg.model.mlp_dim), dropout=float(cfg.model.dropout))
     raise ValueError(f"Unknown model type: {mtype}")

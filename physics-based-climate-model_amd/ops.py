@@ -296,7 +296,7 @@ def gn_silu_bwd(x, gamma, beta, stats, dA, dgamma, dbeta):
     return dx
 
 
-def gn_silu_bwd_gated(x, gamma, beta, stats, a2, dout, gate, dmap, fmap, cnt, s, dpool, dgamma, dbeta, se=None):
+def gn_silu_bwd_gated(x, gamma, beta, stats, a2, dout, gate, dmap, umax, cnt, s, dpool, dgamma, dbeta, se=None):
     """``se`` = (dsig, dz, z, pooled, dw1, dw2) hands the SE weight gradients of the preceding gates_bwd(...,
     defer_se_wgrad=True) to this launch as a side duty (one launch less)."""
     n, c, h, w = x.shape
@@ -304,7 +304,7 @@ def gn_silu_bwd_gated(x, gamma, beta, stats, a2, dout, gate, dmap, fmap, cnt, s,
     sd = se if se is not None else (None,) * 6
     cr = 0 if se is None else se[1].shape[1]
     check(lib.cm_gn_silu_bwd_gated(_p(x), _p(gamma), _p(beta), _p(stats), _p(a2), _p(_contig(dout)), _p(gate),
-                                   _p(dmap), _p(fmap), _p(cnt), _p(s), _p(dpool), _p(dx), _p(dgamma), _p(dbeta), n, c,
+                                   _p(dmap), _p(umax), _p(cnt), _p(s), _p(dpool), _p(dx), _p(dgamma), _p(dbeta), n, c,
                                    h * w, GN_GROUPS, _p(sd[0]), _p(sd[1]), _p(sd[2]), _p(sd[3]), _p(sd[4]), _p(sd[5]), cr,
                                    _stream()), "gn_silu_bwd_gated")
     return dx
@@ -354,13 +354,15 @@ def se_spatial_gate_fwd(a2, pooled, w1, w2, w7, pool_out=False):
 
 
 def gates_bwd(dout, a2, s, z, pooled, gate, fmap, w1, w2, w7, dw1, dw2, dw7, defer_se_wgrad=False):
-    """Backward of SE + spatial gate up to (but excluding) the GroupNorm; returns the maps cm_gn_silu_bwd_gated needs
-    (plus (dsig, dz) when ``defer_se_wgrad``: the SE weight gradients are then left to gn_silu_bwd_gated(se=...))."""
+    """Backward of SE + spatial gate up to (but excluding) the GroupNorm; returns the maps cm_gn_silu_bwd_gated needs:
+    dmap, (umax, cnt), dpool (plus (dsig, dz) when ``defer_se_wgrad``: the SE weight gradients are then left to
+    gn_silu_bwd_gated(se=...)).  (umax, cnt) is the backward's own channel-maximum / tie-count pair."""
     n, c, h, w = a2.shape
     cr = w1.shape[0]
     dev = a2.device
     dgpre = torch.empty(n, h, w, device=dev, dtype=torch.float32)
     cnt = torch.empty(n, h, w, device=dev, dtype=torch.float32)
+    umax = torch.empty(n, h, w, device=dev, dtype=torch.float32)
     dmap = torch.empty(n, 2, h, w, device=dev, dtype=torch.float32)
     ds = torch.empty(n, c, device=dev, dtype=torch.float32)
     dsig = torch.empty(n, c, device=dev, dtype=torch.float32)
@@ -368,18 +370,18 @@ def gates_bwd(dout, a2, s, z, pooled, gate, fmap, w1, w2, w7, dw1, dw2, dw7, def
     dpool = torch.empty(n, c, device=dev, dtype=torch.float32)
     c7ws = torch.empty(int(lib.cm_conv7_bwd_scratch_elems(n, h)), device=dev, dtype=torch.float32)
     st = _stream()
-    check(lib.cm_gate_bwd_reduce(_p(_contig(dout)), _p(a2), _p(s), _p(gate), _p(fmap), _p(dgpre), _p(cnt), n, c, h * w,
+    check(lib.cm_gate_bwd_reduce(_p(_contig(dout)), _p(a2), _p(s), _p(gate), _p(dgpre), _p(cnt), _p(umax), n, c, h * w,
                                  st), "gate_bwd_reduce")
     # dW7 partials are folded by the first workgroups of se_bwd_reduce (one launch less than folding in conv7_bwd)
     check(lib.cm_conv7_bwd(_p(dgpre), _p(fmap), _p(_contig(w7)), _p(dmap), None, _p(c7ws), n, h, w, st), "conv7_bwd")
-    check(lib.cm_se_bwd_reduce(_p(dout), _p(a2), _p(s), _p(gate), _p(dmap), _p(fmap), _p(cnt), _p(ds), n, c, h * w,
+    check(lib.cm_se_bwd_reduce(_p(dout), _p(a2), _p(s), _p(gate), _p(dmap), _p(umax), _p(cnt), _p(ds), n, c, h * w,
                                _p(c7ws), c7ws.numel() // 98, _p(dw7), st), "se_bwd_reduce")
     check(lib.cm_se_excite_bwd(_p(ds), _p(s), _p(z), _p(pooled), _p(_contig(w1)), _p(_contig(w2)), _p(dsig), _p(dz),
                                _p(dpool), None if defer_se_wgrad else _p(dw1), None if defer_se_wgrad else _p(dw2), n, c,
                                cr, st), "se_excite_bwd")
     if defer_se_wgrad:
-        return dmap, cnt, dpool, (dsig, dz)
-    return dmap, cnt, dpool
+        return dmap, (umax, cnt), dpool, (dsig, dz)
+    return dmap, (umax, cnt), dpool
 
 
 # ----------------------------------------------------------------------------------------------------- pool / skip

@@ -37,6 +37,7 @@ class HotPathTrainer:
         self.use_graph = use_graph
         self._graphs = {}
         self._static = {}
+        self._plans = []          # strong references: captured graphs hold raw pointers into these plans' arenas
         self.steps = 0
 
     # ------------------------------------------------------------------ pieces
@@ -45,7 +46,13 @@ class HotPathTrainer:
         g = self.model._views(self.grad)
         check(lib.cm_zero(self._gradbuf.data_ptr(), (self.nt + 1) * 4, torch.cuda.current_stream().cuda_stream),
               "zero")
-        pk = engine.get_plan(p, None, False).pack()
+        plan = engine.get_plan(p, None, False)
+        bplan = engine.get_plan(p, g, False)
+        if not any(q is plan for q in self._plans):
+            self._plans.append(plan)
+        if not any(q is bplan for q in self._plans):
+            self._plans.append(bplan)
+        pk = plan.pack()
         _, sv = engine.forward(p, pk, x, save=True, head=False)
         # output head + MSE + the head's backward: one pass over the last decoder activation
         dd1 = ops.head_mse_bwd(sv.d1, p["head.weight"], p["head.bias"], y, self.loss, g["head.weight"], g["head.bias"])
@@ -88,6 +95,45 @@ class HotPathTrainer:
             ddp.allreduce_gradients(self.grad)
             g2.replay()
         return self.loss
+
+    # ------------------------------------------------------------------ checkpoint / resume
+    def _param_names(self):
+        return [n for n, _ in self.model.named_parameters()]
+
+    def optimizer_state_dict(self) -> dict:
+        """The Adam state in torch.optim.Adam's ``state_dict`` format (per-parameter ``step`` / ``exp_avg`` /
+        ``exp_avg_sq``, parameter indices in ``model.parameters()`` order): what Lightning stores under
+        ``optimizer_states`` for the reference's ``configure_optimizers`` (main_final.py:737-747)."""
+        from .optim import flat_adam_state_dict
+        step = int(self.adam_state[:1].view(torch.int32).item())
+        return flat_adam_state_dict(self.model._build_layout(), self._param_names(), self.model._grad_names,
+                                    self.m, self.v, step, self.lr, self.betas, self.eps, self.wd)
+
+    def load_optimizer_state_dict(self, sd: dict) -> None:
+        """Resume from a torch.optim.Adam-format state (written by ``optimizer_state_dict``, by ``HipAdam`` or by the
+        reference's own optimizer).  Hyper-parameters of the first param group are adopted."""
+        from .optim import load_flat_adam_state
+        step = load_flat_adam_state(sd, self.model._build_layout(), self._param_names(), self.m, self.v)
+        grp = sd["param_groups"][0]
+        self.lr, self.betas = float(grp["lr"]), tuple(grp["betas"])
+        self.eps, self.wd = float(grp["eps"]), float(grp["weight_decay"])
+        st = torch.zeros(4, dtype=torch.float32)
+        st[:1].view(torch.int32)[0] = step            # the device-side counter is an int stored in a float slot
+        self.adam_state.copy_(st)
+        # lr / betas / eps / weight decay are baked into captured graphs as kernel arguments: re-capture on next use
+        self._graphs.clear()
+
+    def state_dict(self) -> dict:
+        return {"model": {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},
+                "optimizer": self.optimizer_state_dict(), "steps": self.steps}
+
+    def load_state_dict(self, sd: dict) -> None:
+        own = self.model.state_dict()
+        with torch.no_grad():
+            for k, v in sd["model"].items():
+                own[k].copy_(v)                      # in place: the flat parameter buffer keeps its address
+        self.load_optimizer_state_dict(sd["optimizer"])
+        self.steps = int(sd.get("steps", 0))
 
     def input_buffers(self, x_shape, y_shape):
         """The static device buffers the replayed graph reads for this batch shape (allocated on first use).  A data

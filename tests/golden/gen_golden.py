@@ -5,7 +5,7 @@ Runs only in the authoring container (needs /root/reference).  The reference's p
 imported under a synthetic package name so that ``src/__init__.py`` (which pulls omegaconf) is skipped
 (SURVEY.md section 8c).  Outputs: small ``.npz`` files next to this script (data only: inputs + expected outputs).
 
-    python tests/golden/gen_golden.py
+    python tests/golden/gen_golden.py [fixture.npz ...]      (no arguments: every fixture)
 """
 import importlib
 import os
@@ -34,6 +34,18 @@ def load_reference():
     return m, u, c
 
 
+def load_reference_factory():
+    """src/models.py (get_model, SimpleCNN) and src/cnn_transformer.py; omegaconf is only used as an annotation there
+    (src/models.py:2,7), so a two-line stand-in module satisfies the import."""
+    if "omegaconf" not in sys.modules:
+        om = types.ModuleType("omegaconf")
+        om.DictConfig = dict
+        sys.modules["omegaconf"] = om
+    mods = importlib.import_module("refsrc.models")
+    ct = importlib.import_module("refsrc.cnn_transformer")
+    return mods, ct
+
+
 def det_tensor(shape, salt, scale=1.0):
     n = int(np.prod(shape))
     k = torch.arange(n, dtype=torch.float64)
@@ -41,7 +53,12 @@ def det_tensor(shape, salt, scale=1.0):
     return (scale * v).reshape(shape).float()
 
 
+ONLY = set(a for a in sys.argv[1:] if a.endswith(".npz"))
+
+
 def npz(name, **arrs):
+    if ONLY and name not in ONLY:
+        return
     out = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrs.items()}
     path = os.path.join(HERE, name)
     np.savez_compressed(path, **out)
@@ -217,6 +234,88 @@ def main():
         names.append(k); sums.append(v.double().sum().item()); firsts.append(v.flatten()[:4].double().numpy())
     npz("init_seed42_base32.npz", names=np.array(names), sums=np.array(sums),
         firsts=np.stack([np.pad(f, (0, 4 - len(f))) for f in firsts]))
+
+    # ---------------------------------------------------------------- default-init model on a left-zero-padded window
+    # (main_final.py:76,127-131: the first seq_len-1 frames of early samples are all-zero IN NORMALISED SPACE; with the
+    #  default init beta = 0, so GroupNorm+SiLU of an all-zero frame is exactly 0 in every channel: C-way amax ties and
+    #  all-equal MaxPool windows on whole frames.)  Tiny so that every gradient can be stored.
+    in_ch, out_ch, base, T, B, H, W = 5, 2, 8, 3, 3, 16, 24
+    torch.manual_seed(42)
+    net = m.AttUNetConvLSTM(in_ch=in_ch, out_ch=out_ch, base=base, seq_len=T)
+    g = torch.Generator("cpu").manual_seed(77)
+    x = torch.randn(B, T, in_ch, H, W, generator=g)
+    x[0, :T - 1] = 0.0                 # sample 0: only the last frame is real
+    x[1, :1] = 0.0                     # sample 1: one padded frame
+    yt = torch.randn(B, out_ch, H, W, generator=g)
+    xg = x.clone().requires_grad_()
+    pred = net(xg); loss = F.mse_loss(pred, yt); loss.backward()
+    arrs = dict(x=x, y=yt, cfg=np.array([in_ch, out_ch, base, T, B, H, W]), pred=pred, loss=loss, dx=xg.grad)
+    for k, v in net.state_dict().items():
+        arrs["p." + k] = v.clone()
+    for k, p_ in net.named_parameters():
+        if p_.grad is not None:
+            arrs["g." + k] = p_.grad.clone()
+    npz("model_default_init_padded.npz", **arrs)
+
+    # ---------------------------------------------------------------- same situation at BASELINE config 2's shape
+    # (checksums only): default init under seed 42, 1/8 of the samples with their first T-1 frames zeroed.
+    in_ch, out_ch, base, T, B, H, W = 5, 2, 32, 6, 32, 48, 72
+    torch.manual_seed(42)
+    net = m.AttUNetConvLSTM(in_ch=in_ch, out_ch=out_ch, base=base, seq_len=T)
+    g = torch.Generator("cpu").manual_seed(4321)
+    x = torch.randn(B, T, in_ch, H, W, generator=g)
+    x[::8, :T - 1] = 0.0
+    yt = torch.randn(B, out_ch, H, W, generator=g)
+    pred = net(x); loss = F.mse_loss(pred, yt); loss.backward()
+    idx = torch.linspace(0, pred.numel() - 1, 64).long()
+    arrs = dict(cfg=np.array([in_ch, out_ch, base, T, B, H, W]), seed=np.array(4321), loss=loss,
+                pred_l2=pred.double().norm(), pred_samples=pred.flatten()[idx], pred_sample_idx=idx)
+    names, norms, samples = [], [], []
+    for k, p_ in net.named_parameters():
+        if p_.grad is None:
+            continue
+        names.append(k); norms.append(p_.grad.double().norm().item())
+        ii = torch.linspace(0, p_.numel() - 1, 8).long()
+        samples.append(p_.grad.flatten()[ii].numpy())
+    arrs.update(grad_names=np.array(names), grad_l2=np.array(norms), grad_samples=np.stack(samples))
+    npz("cfg2_default_init_padded_checksums.npz", **arrs)
+
+    # ---------------------------------------------------------------- plain UNet (src/unet.py:72-109), tiny
+    in_ch, out_ch, base, B, H, W = 5, 2, 8, 2, 16, 24
+    params = oracle.closed_form_params(in_ch, out_ch, base, salt=2, shapes=oracle.unet_param_shapes(in_ch, out_ch, base))
+    net = u.UNet(in_ch=in_ch, out_ch=out_ch, base=base)
+    net.load_state_dict(params)
+    x = det_tensor((B, in_ch, H, W), 70.0).requires_grad_()
+    yt = det_tensor((B, out_ch, H, W), 71.0)
+    pred = net(x); loss = F.mse_loss(pred, yt); loss.backward()
+    arrs = dict(x=x, y=yt, cfg=np.array([in_ch, out_ch, base, B, H, W]), salt=np.array(2), pred=pred, loss1=loss,
+                dx=x.grad, names=np.array(list(net.state_dict().keys())))
+    for k, p_ in net.named_parameters():
+        arrs["g." + k] = p_.grad.clone()
+    npz("unet_tiny.npz", **arrs)
+
+    # ---------------------------------------------------------------- SimpleCNN (src/models.py:44-123) + factory
+    mods, ct = load_reference_factory()
+    torch.manual_seed(42)
+    net = mods.SimpleCNN(n_input_channels=5, n_output_channels=2, kernel_size=3, init_dim=8, depth=3, dropout_rate=0.2)
+    names, shapes_, sums = [], [], []
+    for k, v in net.state_dict().items():
+        names.append(k); shapes_.append(np.pad(np.array(v.shape, dtype=np.int64), (0, 4 - v.dim())))
+        sums.append(v.double().sum().item())
+    x = det_tensor((2, 5, 8, 12), 80.0)
+    net.eval()
+    y_eval = net(x)
+    net.train()
+    torch.manual_seed(7)               # Dropout2d mask stream
+    xg = x.clone().requires_grad_()
+    y_train = net(xg); y_train.square().mean().backward()
+    npz("simple_cnn.npz", names=np.array(names), shapes=np.stack(shapes_), sums=np.array(sums), x=x, y_eval=y_eval,
+        y_train=y_train, dx_train=xg.grad, g_initial0=net.initial[0].weight.grad,
+        bn_running_mean=net.initial[1].running_mean)
+    # factory smoke: default YAML values of configs/model/SimpleCNN.yaml (10.73 M parameters)
+    net = mods.SimpleCNN(n_input_channels=5, n_output_channels=2, kernel_size=3, init_dim=64, depth=4, dropout_rate=0.2)
+    npz("simple_cnn_default_cfg.npz", n_params=np.array(sum(p_.numel() for p_ in net.parameters())),
+        names=np.array(list(net.state_dict().keys())))
 
 
 if __name__ == "__main__":

@@ -19,7 +19,7 @@ def test_cabi_library_exports_every_declared_symbol():
     dll = lib.load()
     for name in protos:
         assert hasattr(dll, name), name
-    assert lib.cm_version() == 2 and lib.cm_arch() == b"gfx950"
+    assert lib.cm_version() == 3 and lib.cm_arch() == b"gfx950"
     # pure host-side helpers work without a GPU
     assert lib.cm_conv3x3_packed_elems(5, 32) == 16 * 9 * 32
     assert 0 <= lib.cm_conv3x3_pick_config(192, 48, 72, 32) < lib.cm_conv3x3_num_configs()
@@ -106,10 +106,126 @@ def test_factory_and_config_surface():
     cfg.model["type"] = "does_not_exist"
     with pytest.raises(ValueError, match="Unknown model type: does_not_exist"):
         get_model(cfg)
-    cfg.model["type"] = "SimpleCNN"
-    with pytest.raises(NotImplementedError):
-        get_model(cfg)
     assert get_model(synthetic_config(base_channels=32)).base == 32
+
+
+def test_factory_serves_every_reference_model_type():
+    """src/models.py:7-38 dispatches on four model.type values; replacing the reference's factory must not break any
+    of them (SimpleCNN = BASELINE configs[0], stock torch; unet = the same HIP kernels on one frame)."""
+    import climate_amd
+    from climate_amd.config import load_config
+    from climate_amd.host_models import SimpleCNN
+    from climate_amd.model import UNet, get_model
+    cdir = os.path.join(climate_amd._PKG_DIR, "configs")
+    g = load_golden("simple_cnn_default_cfg.npz")
+    m = get_model(load_config(cdir, overrides=["model=SimpleCNN"]))
+    assert isinstance(m, SimpleCNN)
+    assert sum(p.numel() for p in m.parameters()) == int(g["n_params"]) == 10730626     # BASELINE.md section 2
+    assert list(m.state_dict()) == g["names"].tolist()
+    y = m.eval()(torch.zeros(2, 5, 16, 24))                                            # plumbing: runs on the CPU
+    assert y.shape == (2, 2, 16, 24)
+    u = get_model(load_config(cdir, overrides=["model=unet", "model.base_channels=8"]))
+    assert isinstance(u, UNet) and u.base == 8
+    want = oracle.unet_param_shapes(5, 2, 8)
+    assert list(u.state_dict()) == list(want) == load_golden("unet_tiny.npz")["names"].tolist()
+    assert all(tuple(v.shape) == want[k] for k, v in u.state_dict().items())
+    assert u._grad_names == list(want)                                                   # every parameter is trained
+    with pytest.raises(RuntimeError, match="HIP path only"):
+        u(torch.zeros(1, 5, 8, 8))
+
+
+def test_simple_cnn_matches_reference():
+    """Stock-torch SimpleCNN restatement vs the reference's (src/models.py:44-123): default init under a seed, eval
+    forward, train-mode forward/backward (BatchNorm batch statistics + the Dropout2d mask stream)."""
+    from climate_amd.host_models import SimpleCNN
+    g = load_golden("simple_cnn.npz")
+    torch.manual_seed(42)
+    m = SimpleCNN(n_input_channels=5, n_output_channels=2, kernel_size=3, init_dim=8, depth=3, dropout_rate=0.2)
+    sd = m.state_dict()
+    assert list(sd) == g["names"].tolist()
+    for k, shp, sm in zip(g["names"].tolist(), g["shapes"], g["sums"].tolist()):
+        assert tuple(sd[k].shape) == tuple(int(v) for v in shp[:sd[k].dim()])
+        assert abs(sd[k].double().sum().item() - sm) < 1e-9, k
+    x = g["x"]
+    m.eval()
+    assert torch.allclose(m(x), g["y_eval"], rtol=0, atol=1e-6)
+    m.train()
+    torch.manual_seed(7)
+    xg = x.clone().requires_grad_()
+    y = m(xg); y.square().mean().backward()
+    assert torch.allclose(y, g["y_train"], rtol=0, atol=1e-6)
+    assert torch.allclose(xg.grad, g["dx_train"], rtol=1e-5, atol=1e-7)
+    assert torch.allclose(m.initial[0].weight.grad, g["g_initial0"], rtol=1e-5, atol=1e-7)
+    assert torch.allclose(m.initial[1].running_mean, g["bn_running_mean"], rtol=0, atol=1e-7)
+
+
+def test_hip_adam_state_interoperates_with_torch_adam():
+    """HipAdam's optimizer state has torch.optim.Adam's layout: a reference checkpoint's optimizer state
+    loads into HipAdam and vice versa (Lightning restores it on ckpt_path= resume, main_final.py:770-774)."""
+    from climate_amd.model import AttUNetConvLSTM
+    from climate_amd.optim import HipAdam
+    torch.manual_seed(0)
+    m = AttUNetConvLSTM(5, 2, 8)
+    ref = torch.optim.Adam(m.parameters(), lr=5e-4, weight_decay=0.0)
+    for n, p in m.named_parameters():
+        if not n.startswith("post_conv."):
+            p.grad = torch.randn_like(p)
+    ref.step(); ref.step()
+    sd = ref.state_dict()
+    ours = HipAdam(m.parameters(), lr=1e-3)
+    ours.load_state_dict(sd)                                   # reference -> ours
+    assert ours.param_groups[0]["lr"] == 5e-4
+    named = dict(m.named_parameters())
+    st = ours.state[named["enc1.body.0.weight"]]
+    assert torch.is_tensor(st["step"]) and float(st["step"]) == 2.0
+    assert st["exp_avg"].shape == named["enc1.body.0.weight"].shape
+    assert named["post_conv.0.weight"] not in ours.state or not ours.state[named["post_conv.0.weight"]]
+    back = torch.optim.Adam(m.parameters(), lr=1e-3)
+    back.load_state_dict(ours.state_dict())                    # ours -> reference
+    for a, b in zip(sd["state"].values(), back.state_dict()["state"].values()):
+        assert torch.equal(a["exp_avg"], b["exp_avg"]) and torch.equal(a["exp_avg_sq"], b["exp_avg_sq"])
+        assert float(a["step"]) == float(b["step"])
+    assert set(sd["param_groups"][0]) == set(ours.state_dict()["param_groups"][0])
+
+
+def test_flat_adam_state_roundtrip_against_torch_adam():
+    """The fused trainer's flat moment buffers <-> torch.optim.Adam's state_dict (pure host logic, CPU tensors)."""
+    from climate_amd.model import AttUNetConvLSTM
+    from climate_amd.optim import flat_adam_state_dict, load_flat_adam_state
+    torch.manual_seed(1)
+    m = AttUNetConvLSTM(5, 2, 8)
+    names = [n for n, _ in m.named_parameters()]
+    ref = torch.optim.Adam(m.parameters(), lr=5e-4)
+    for n, p in m.named_parameters():
+        if not n.startswith("post_conv."):
+            p.grad = torch.randn_like(p)
+    for _ in range(3):
+        ref.step()
+    sd = ref.state_dict()
+    lay, nt = m._build_layout(), m.n_flat_trainable
+    fm, fv = torch.full((nt,), 9.0), torch.full((nt,), 9.0)
+    assert load_flat_adam_state(sd, lay, names, fm, fv) == 3
+    o, k, shp = lay["up2.conv.body.3.weight"]
+    idx = names.index("up2.conv.body.3.weight")
+    assert torch.equal(fm[o:o + k].view(shp), sd["state"][idx]["exp_avg"])
+    out = flat_adam_state_dict(lay, names, m._grad_names, fm, fv, 3, 5e-4, (0.9, 0.999), 1e-8, 0.0)
+    assert set(out["state"]) == set(sd["state"]) and len(out["state"]) == 73
+    for i in sd["state"]:
+        assert torch.equal(out["state"][i]["exp_avg_sq"], sd["state"][i]["exp_avg_sq"])
+        assert float(out["state"][i]["step"]) == 3.0
+    fresh = torch.optim.Adam(m.parameters(), lr=1e-3)
+    fresh.load_state_dict(out)                                 # torch accepts what the fused trainer writes
+    assert fresh.param_groups[0]["lr"] == 5e-4
+    assert flat_adam_state_dict(lay, names, m._grad_names, fm, fv, 0, 5e-4, (0.9, 0.999), 1e-8, 0.0)["state"] == {}
+
+
+def test_plan_cache_keeps_referenced_plans():
+    """engine.get_plan's LRU never evicts a plan something else still holds (captured graphs point into its arenas)."""
+    import sys
+    from climate_amd import engine
+    assert engine._PLANS_MAX >= 2
+    src = open(engine.__file__).read()
+    assert "getrefcount" in src and "_PLANS.clear()" not in src
 
 
 def test_product_path_has_no_cpu_fallback():

@@ -243,7 +243,7 @@ def _gates_roundtrip(ops, a2, w1, w2, w7, dout, gamma=None, beta=None, y2=None):
     z, s = ops.se_excite_fwd(dev(pooled), dev(w1), dev(w2))
     out, fmap, gate = ops.spatial_gate_fwd(dev(a2), s, dev(w7))
     dw1 = torch.zeros_like(dev(w1)); dw2 = torch.zeros_like(dev(w2)); dw7 = torch.zeros_like(dev(w7))
-    dmap, cnt, dpool = ops.gates_bwd(dev(dout), dev(a2), s, z, dev(pooled), gate, fmap, dev(w1), dev(w2), dev(w7), dw1,
+    dmap, (umax, cnt), dpool = ops.gates_bwd(dev(dout), dev(a2), s, z, dev(pooled), gate, fmap, dev(w1), dev(w2), dev(w7), dw1,
                                      dw2, dw7)
     return out, (s, fmap, gate, dmap, cnt, dpool), dw1, dw2, dw7
 
@@ -295,9 +295,9 @@ def test_conv_block_chain_golden(ops, defer):
     res = ops.gates_bwd(dy, a2, s, z, pooled, gate, fmap, P["se.fc.0.weight"], P["se.fc.2.weight"],
                         P["spat.conv.weight"], G["se.fc.0.weight"], G["se.fc.2.weight"], G["spat.conv.weight"],
                         defer_se_wgrad=defer)
-    dmap, cnt, dpool = res[:3]
+    dmap, (umax, cnt), dpool = res[:3]
     se = (res[3][0], res[3][1], z, pooled, G["se.fc.0.weight"], G["se.fc.2.weight"]) if defer else None
-    dy2 = ops.gn_silu_bwd_gated(y2, P["body.4.weight"], P["body.4.bias"], st2, a2, dy, gate, dmap, fmap, cnt, s, dpool,
+    dy2 = ops.gn_silu_bwd_gated(y2, P["body.4.weight"], P["body.4.bias"], st2, a2, dy, gate, dmap, umax, cnt, s, dpool,
                                 G["body.4.weight"], G["body.4.bias"], se=se)
     gw = torch.zeros(co, 9, co, device="cuda")
     ops.wgrad3x3(a1, dy2, gw)
@@ -377,7 +377,8 @@ def test_gates_bwd_wide_images(ops):
     dout = torch.randn(n, c, h, w, device="cuda")
     out, z, s, fmap, gate = ops.se_spatial_gate_fwd(a2, pooled, w1, w2, w7)
     dw1 = torch.zeros_like(w1); dw2 = torch.zeros_like(w2); dw7 = torch.zeros_like(w7)
-    dmap, cnt, dpool = ops.gates_bwd(dout, a2, s, z, pooled, gate, fmap, w1, w2, w7, dw1, dw2, dw7)
+    dmap, (umax, cnt), dpool = ops.gates_bwd(dout, a2, s, z, pooled, gate, fmap, w1, w2, w7, dw1, dw2, dw7)
+    assert torch.equal(umax, fmap[:, 1])        # the backward's own maximum is the forward's, bit for bit
     U = a2 * s[:, :, None, None]
     assert torch.equal(cnt, (U == fmap[:, 1:2]).float().sum(1))
     dgpre = (dout * U).sum(1) * gate * (1.0 - gate)
@@ -401,7 +402,7 @@ def test_gates_ties_backward(ops):
     out, fmap, gate = ops.spatial_gate_fwd(dev(a2), s, dev(w7))
     assert rel_l2(out, g["y"]) < TOL
     dw1 = torch.zeros_like(dev(w1)); dw2 = torch.zeros_like(dev(w2)); dw7 = torch.zeros_like(dev(w7))
-    dmap, cnt, dpool = ops.gates_bwd(dev(dy), dev(a2), s, z, dev(pooled), gate, fmap, dev(w1), dev(w2), dev(w7), dw1,
+    dmap, (umax, cnt), dpool = ops.gates_bwd(dev(dy), dev(a2), s, z, dev(pooled), gate, fmap, dev(w1), dev(w2), dev(w7), dw1,
                                      dw2, dw7)
     assert rel_l2(dw7, g["dw7"]) < TOL
     # identity "GroupNorm": use gn bwd gated with a real GN whose output we then compare through autograd instead;

@@ -131,3 +131,85 @@ def test_cfg2_checksums():
     assert abs(pred.double().norm().item() - float(g["pred_l2"])) < 1e-5 * float(g["pred_l2"])
     for name, want in zip(g["grad_names"].tolist(), g["grad_l2"].tolist()):
         assert abs(p[name].grad.double().norm().item() - want) <= 5e-5 * want + 1e-12, name
+
+
+def test_default_init_left_padded_window_vs_reference():
+    """Default init (beta = 0) + all-zero leading frames (main_final.py:76,127-131): whole frames of exact C-way amax
+    ties and all-equal MaxPool windows.  Oracle forward, loss and all 73 gradients vs the reference's."""
+    g = load_golden("model_default_init_padded.npz")
+    p = {k: v.clone().requires_grad_() for k, v in _sub(g, "p.").items()}
+    x = g["x"].clone().requires_grad_()
+    pred = oracle.model_forward(p, x)
+    assert rel_l2(pred, g["pred"]) < TOL
+    loss = F.mse_loss(pred, g["y"]); loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-6 * float(g["loss"])
+    assert rel_l2(x.grad, g["dx"]) < 1e-5
+    for k, want in _sub(g, "g.").items():
+        assert rel_l2(p[k].grad, want) < 1e-5, k
+    assert p["post_conv.0.weight"].grad is None
+
+
+def test_plain_unet_vs_reference():
+    g = load_golden("unet_tiny.npz")
+    in_ch, out_ch, base = (int(v) for v in g["cfg"][:3])
+    P = oracle.closed_form_params(in_ch, out_ch, base, salt=int(g["salt"]),
+                                  shapes=oracle.unet_param_shapes(in_ch, out_ch, base))
+    assert list(P) == g["names"].tolist()
+    p = {k: v.clone().requires_grad_() for k, v in P.items()}
+    x = g["x"].clone().requires_grad_()
+    pred = oracle.unet_forward(p, x)
+    assert rel_l2(pred, g["pred"]) < TOL
+    F.mse_loss(pred, g["y"]).backward()
+    assert rel_l2(x.grad, g["dx"]) < 1e-5
+    for k, want in _sub(g, "g.").items():
+        assert rel_l2(p[k].grad, want) < 1e-5, k
+
+
+def test_imposed_decisions_are_neutral_when_they_are_the_oracles_own():
+    """oracle.Decisions with the oracle's own amax masks / MaxPool choices reproduces the plain gradient exactly and
+    reports no differing / violating site; a wrong choice is counted as a violation."""
+    import oracle.cpu_ref as ref
+    P = {k: v.double().requires_grad_() for k, v in oracle.closed_form_params(5, 2, 8).items()}
+    gen = torch.Generator("cpu").manual_seed(3)
+    x = torch.randn(2, 3, 5, 16, 24, generator=gen).double()
+    y = torch.randn(2, 2, 16, 24, generator=gen).double()
+    oracle.training_loss(P, x, y).backward()
+    g0 = {k: v.grad.clone() for k, v in P.items() if v.grad is not None}
+    gate_in, pool_in = [], []
+    o_sg, o_mp = ref.spatial_gate, ref._max_pool
+
+    def sg(xx, w7, dec=None, site=None):
+        gate_in.append(xx.detach())
+        return o_sg(xx, w7, dec, site)
+
+    def mp(xx, dec, site):
+        pool_in.append((site, xx.detach()))
+        return o_mp(xx, dec, site)
+    ref.spatial_gate, ref._max_pool = sg, mp
+    try:
+        with torch.no_grad():
+            oracle.model_forward(P, x)
+    finally:
+        ref.spatial_gate, ref._max_pool = o_sg, o_mp
+    sites = [(pfx, t) for t in range(3) for pfx in ("enc1.", "enc2.conv.", "enc3.conv.", "enc4.conv.")]
+    sites += [("up3.conv.", None), ("up2.conv.", None), ("up1.conv.", None)]
+    dec = oracle.Decisions()
+    for site, u in zip(sites, gate_in):
+        dec.amax[site] = u == u.amax(1, keepdim=True)
+    for site, v in pool_in:
+        n, c, h, w = v.shape
+        win = v.view(n, c, h // 2, 2, w // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, c, h // 2, w // 2, 4)
+        dec.pool[site] = win.argmax(-1)
+    for v in P.values():
+        v.grad = None
+    oracle.training_loss(P, x, y, decisions=dec).backward()
+    assert dec.violations == 0 and dec.differing == 0 and dec.sites > 0
+    for k in g0:
+        assert torch.equal(P[k].grad, g0[k]), k
+    bad = oracle.Decisions()
+    wrong = dec.amax[("up1.conv.", None)].clone()
+    u = gate_in[-1]
+    wrong[0, :, 0, 0] = u[0, :, 0, 0] == u[0, :, 0, 0].amin()       # impose the MINIMUM channel at one pixel
+    bad.amax[("up1.conv.", None)] = wrong
+    oracle.model_forward(P, x, decisions=bad)
+    assert bad.violations >= 1

@@ -40,10 +40,10 @@ print("fwd: y1 %.1e a1 %.1e y2 %.1e a2 %.1e pooled %.1e s %.1e fmap %.1e gate %.
     rel(Y1, y1), rel(A1, a1), rel(Y2, y2), rel(A2, a2), rel(PO, pooled.flatten(1)), rel(S, s.flatten(1)), rel(FM, fmap),
     rel(GT, gate.squeeze(1)), rel(OUT, out)))
 G = {k: torch.zeros_like(D(v)) for k, v in P.items()}
-dmap, cnt, dpool = ops.gates_bwd(D(dout), A2, S, Z, PO, GT, FM, D(S1), D(S2), D(W7), G["S1"], G["S2"], G["W7"])
+dmap, (umax, cnt), dpool = ops.gates_bwd(D(dout), A2, S, Z, PO, GT, FM, D(S1), D(S2), D(W7), G["S1"], G["S2"], G["W7"])
 print("bwd maps: dmap %.1e dpool %.1e  dS1 %.1e dS2 %.1e dW7 %.1e" % (rel(dmap, fmap.grad), rel(dpool, pooled.grad.flatten(1)),
       rel(G["S1"], R["S1"].grad), rel(G["S2"], R["S2"].grad), rel(G["W7"], R["W7"].grad)))
-DY2 = ops.gn_silu_bwd_gated(Y2, D(g2), D(b2), st2, A2, D(dout), GT, dmap, FM, cnt, S, dpool, G["g2"], G["b2"])
+DY2 = ops.gn_silu_bwd_gated(Y2, D(g2), D(b2), st2, A2, D(dout), GT, dmap, umax, cnt, S, dpool, G["g2"], G["b2"])
 print("gn2 bwd: dy2 %.1e dg2 %.1e db2 %.1e" % (rel(DY2, y2.grad), rel(G["g2"], R["g2"].grad), rel(G["b2"], R["b2"].grad)))
 gw = torch.zeros(co, 9, co, device="cuda"); ops.wgrad3x3(A1, DY2, gw)
 DA1 = ops.conv3x3(DY2, ops.pack_conv3x3(D(W2), dgrad=True), co)
@@ -57,12 +57,12 @@ print("conv1 bwd: dW1 %.1e" % rel(ops.wgrad3x3_unpack(gw), R["W1"].grad))
 from climate_amd._lib import lib, check
 st = torch.cuda.current_stream().cuda_stream
 hw = h * w
-dgpre = torch.empty(n, h, w, device="cuda"); cnt2 = torch.empty(n, h, w, device="cuda")
-check(lib.cm_gate_bwd_reduce(D(dout).data_ptr(), A2.data_ptr(), S.data_ptr(), GT.data_ptr(), FM.data_ptr(), dgpre.data_ptr(), cnt2.data_ptr(), n, co, hw, st))
+dgpre = torch.empty(n, h, w, device="cuda"); cnt2 = torch.empty(n, h, w, device="cuda"); um2 = torch.empty(n, h, w, device="cuda")
+check(lib.cm_gate_bwd_reduce(D(dout).data_ptr(), A2.data_ptr(), S.data_ptr(), GT.data_ptr(), dgpre.data_ptr(), cnt2.data_ptr(), um2.data_ptr(), n, co, hw, st))
 dmap2 = torch.empty(n, 2, h, w, device="cuda"); dw7 = torch.zeros(98, device="cuda")
 check(lib.cm_conv7_bwd(dgpre.data_ptr(), FM.data_ptr(), D(W7).data_ptr(), dmap2.data_ptr(), dw7.data_ptr(), torch.empty(int(lib.cm_conv7_bwd_scratch_elems(n, h)), device='cuda').data_ptr(), n, h, w, st))
 ds = torch.empty(n, co, device="cuda")
-check(lib.cm_se_bwd_reduce(D(dout).data_ptr(), A2.data_ptr(), S.data_ptr(), GT.data_ptr(), dmap2.data_ptr(), FM.data_ptr(), cnt2.data_ptr(), ds.data_ptr(), n, co, hw, None, 0, None, st))
+check(lib.cm_se_bwd_reduce(D(dout).data_ptr(), A2.data_ptr(), S.data_ptr(), GT.data_ptr(), dmap2.data_ptr(), um2.data_ptr(), cnt2.data_ptr(), ds.data_ptr(), n, co, hw, None, 0, None, st))
 print("ds %.2e  cnt max %d  dgpre %.1e" % (rel(ds, s.grad.flatten(1)), int(cnt2.max().item()), rel(dgpre, (fmap.grad * 0 + 0).sum(1) if False else dgpre)))
 dsr = s.grad.flatten(1)
 print("per (n,c) rel:", [f"{((ds[i//co, i%co].item()-dsr[i//co,i%co].item())/abs(dsr[i//co,i%co].item())):.1e}" for i in range(min(n*co, 32))])
