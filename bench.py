@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """Headline benchmark: training samples/s of unet_convlstm_attention (BASELINE.json configs[1]) on N MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]          (N>1: launched by torch.distributed.run)
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py --base 64 --seq-len 12                               (BASELINE configs[2], one rank's share)
+    python bench.py --base 64 --height 192 --width 288 --batch 16        (BASELINE configs[4], one rank's share)
+
+N > 1 works both ways: under ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` (RANK /
+WORLD_SIZE come from the launcher), and as a plain ``python bench.py --gpus N``, which starts the N rank processes
+itself (children, before anything touches a GPU in the parent; the parent only forwards rank 0's JSON line).
 
 One "step" = zero grads -> forward -> MSE -> backward -> (RCCL all-reduce) -> Adam on one synthetic batch of
 [32, 6, 5, 48, 72] per GPU (weak scaling), fp32, inputs resident in HBM.  Rank 0 prints ONE JSON line.
@@ -54,6 +60,12 @@ def train_flops_per_sample(b, T, H, W, cin=5, cout=2):
     return 3 * (T * enc + T * lstm + dec + head)
 
 
+def _which_config(base, T, H, W):
+    key = (base, T, H, W)
+    return {(32, 6, 48, 72): "BASELINE.json configs[1]", (64, 12, 48, 72): "BASELINE.json configs[2], one rank's share",
+            (64, 6, 192, 288): "BASELINE.json configs[4], one rank's share"}.get(key, "not a BASELINE.json config")
+
+
 def usable_cores():
     """CPU cores this process may really use: affinity mask capped by the cgroup CPU quota (containers)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -100,6 +112,33 @@ def cpu_baseline(cfg, steps=5):
                       f"[{B},{T},{C},{H},{W}] base={base} after 1 warm-up; median step {med * 1e3:.0f} ms"}
 
 
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher environment: start N rank processes (one per GPU, RCCL over
+    127.0.0.1) as children.  Nothing in this parent touches the GPU (torch.cuda.device_count() does not initialise
+    it on this image); it relays rank 0's stdout and returns the worst exit code."""
+    import socket
+    import subprocess
+    n = args.gpus
+    have = torch.cuda.device_count()
+    if args.backend in (None, "nccl") and have < n:
+        raise SystemExit(f"--gpus {n} but only {have} GPU(s) visible (use --backend gloo for a shared-GPU rehearsal)")
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    raise SystemExit(max(abs(rc) for rc in rcs))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,12 +147,16 @@ def main():
     ap.add_argument("--base", type=int, default=32)
     ap.add_argument("--seq-len", type=int, default=6)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--height", type=int, default=48)
+    ap.add_argument("--width", type=int, default=72)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); 'gloo' allows a "
                     "multi-process rehearsal on a single GPU")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args, sys.argv[1:])
 
     from climate_amd import ddp
     from climate_amd.config import synthetic_config
@@ -131,12 +174,13 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    B, T, C, H, W, base = args.batch, args.seq_len, 5, 48, 72, args.base
+    B, T, C, H, W, base = args.batch, args.seq_len, 5, args.height, args.width, args.base
     cfg = synthetic_config(base_channels=base, seq_len=T)
     torch.manual_seed(cfg.seed)
     model = get_model(cfg).to(dev)
     gen = torch.Generator("cpu").manual_seed(1234 + rank)
-    x = torch.randn(B, T, C, H, W, generator=gen).to(dev)
+    x_host = torch.randn(B, T, C, H, W, generator=gen)
+    x = x_host.to(dev)
     y = torch.randn(B, 2, H, W, generator=gen).to(dev)
     tr = HotPathTrainer(model, lr=cfg.training.lr, weight_decay=cfg.training.weight_decay,
                         use_graph=not args.no_graph)
@@ -165,6 +209,32 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     final_loss = loss.item()
+
+    # ---- forward-only throughput and the PCIe leg of a host-resident batch (never part of `value`) -----
+    fwd_sps, h2d = None, None
+    if rank == 0:
+        from climate_amd.trainer import InferenceRunner
+        inf = InferenceRunner(model, use_graph=not args.no_graph)
+        for _ in range(3):
+            inf(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nf = max(5, args.steps // 2)
+        for _ in range(nf):
+            inf(x)
+        torch.cuda.synchronize()
+        fwd_sps = B * nf / (time.perf_counter() - t0)
+        pinned = x_host.pin_memory()
+        sx.copy_(pinned, non_blocking=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            sx.copy_(pinned, non_blocking=True)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 5 * 1e3
+        h2d = {"ms_per_batch": round(ms, 3), "gbps": round(x_host.numel() * 4 / (ms * 1e-3) / 1e9, 1),
+               "bytes": x_host.numel() * 4, "note": "pinned host batch -> trainer input buffer; excluded from value"}
+        sx.copy_(x_host.to(dev))
 
     # ---- roofline pass: same workload, eager launches, HIP events around every launcher --------------------------
     roof, kernels = None, {}
@@ -204,23 +274,28 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(dict(B=B, T=T, C=C, H=H, W=W, base=base))
+        # bounded sample: the default workload runs whole (5 steps, ~1.5 s on 16 cores); larger ones are cut to a
+        # sub-batch that keeps the CPU leg near 20 s (throughput is per sample; the oracle has no cross-sample term)
+        cost = train_flops_per_sample(base, T, H, W) * B
+        cb = B if cost < 1e12 else max(1, int(B * 1e12 / cost))
+        cpu = cpu_baseline(dict(B=cb, T=T, C=C, H=H, W=W, base=base), steps=5 if cost < 1e12 else 2)
 
     if rank == 0:
         gb = B * world
         value = gb * args.steps / dt
         fl = train_flops_per_sample(base, T, H, W)
         out = {
-            "metric": "training samples/sec (seq_len=6, 48x72 grid)", "value": round(value, 2), "unit": "samples/s",
+            "metric": f"training samples/sec (seq_len={T}, {H}x{W} grid)", "value": round(value, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"unet_convlstm_attention base={base} seq_len={T} 48x72 5->2, "
-                                   f"per-GPU batch {B} (BASELINE.json configs[1]), fwd+MSE+bwd+all-reduce+Adam",
+            "config": {"workload": f"unet_convlstm_attention base={base} seq_len={T} {H}x{W} 5->2, "
+                                   f"per-GPU batch {B} ({_which_config(base, T, H, W)}), fwd+MSE+bwd+all-reduce+Adam",
                        "global_batch": gb, "seq_len": T, "parallelism": f"dp{world}",
                        "hip_graph": not args.no_graph},
             "step_mfma_frac": round(value / world * fl / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
             "final_loss": final_loss,
+            "fwd_samples_per_s": None if fwd_sps is None else round(fwd_sps, 1), "h2d": h2d,
             "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
         }
         print(json.dumps(out))

@@ -53,10 +53,10 @@ class HotPathTrainer:
         if not any(q is bplan for q in self._plans):
             self._plans.append(bplan)
         pk = plan.pack()
-        _, sv = engine.forward(p, pk, x, save=True, head=False)
+        _, sv = self.model._engine_forward(p, pk, x, save=True, head=False)
         # output head + MSE + the head's backward: one pass over the last decoder activation
         dd1 = ops.head_mse_bwd(sv.d1, p["head.weight"], p["head.bias"], y, self.loss, g["head.weight"], g["head.bias"])
-        engine.backward(p, pk, g, sv, None, need_dx=False, dd1=dd1)
+        self.model._engine_backward(p, pk, g, sv, None, need_dx=False, dd1=dd1)
 
     def _adam(self):
         b1, b2 = self.betas
@@ -172,3 +172,52 @@ class HotPathTrainer:
             with torch.cuda.graph(g2):
                 self._adam()
         self._graphs[key] = (g1, g2)
+
+
+class InferenceRunner:
+    """Forward only, no autograd state: what ``validation_step`` / ``test_step`` need from the model
+    (main_final.py:563-574,684-690: ``self(x)`` under no_grad).  {pack weights, forward} is recorded once per input
+    shape into a hipGraph and replayed; the returned prediction tensor is the graph's static output (copy it if it
+    must survive the next call)."""
+
+    def __init__(self, model, use_graph: bool = True):
+        self.model = model
+        self.use_graph = use_graph
+        self._graphs = {}
+        self._plans = []
+
+    def _fwd(self, x):
+        p = self.model._param_dict()
+        plan = engine.get_plan(p, None, False)
+        if not any(q is plan for q in self._plans):
+            self._plans.append(plan)
+        pred, _ = self.model._engine_forward(p, plan.pack(), x, save=False)
+        return pred
+
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda:
+            raise RuntimeError("batch must be on the GPU")
+        x = x.contiguous()
+        if not self.use_graph:
+            return self._fwd(x)
+        key = tuple(x.shape)
+        if key not in self._graphs:
+            sx = torch.empty_like(x)
+            sx.copy_(x)
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self._fwd(sx)              # autotune + allocator warm-up outside the capture
+                self._fwd(sx)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self._fwd(sx)
+            self._graphs[key] = (g, sx, out)
+        g, sx, out = self._graphs[key]
+        if x.data_ptr() != sx.data_ptr():
+            sx.copy_(x, non_blocking=True)
+        g.replay()
+        return out

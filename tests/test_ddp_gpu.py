@@ -1,5 +1,7 @@
-"""Two ranks (gloo rehearsal of the RCCL path, both on cuda:0) must reproduce the single-process step on the
-concatenated batch: shard -> local fwd/bwd -> SUM all-reduce of the flat gradient -> Adam with grad_scale 1/world."""
+"""Two ranks must reproduce the single-process step on the concatenated batch: shard -> local fwd/bwd -> SUM
+all-reduce of the flat gradient -> Adam with grad_scale 1/world.  backend "gloo": rehearsal of the exchange logic with
+both ranks on cuda:0 (runs on a one-GPU box); backend "nccl": the real thing, RCCL over xGMI, one rank per GPU
+(skipped unless the box has two GPUs)."""
 import os
 import socket
 
@@ -32,13 +34,14 @@ def _model():
     return m.cuda()
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, backend):
+    local = rank if backend == "nccl" else 0
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0")
+                      LOCAL_RANK=str(local), HSA_ENABLE_IPC_MODE_LEGACY="0")
     from climate_amd import ddp
     from climate_amd.trainer import HotPathTrainer
-    ddp.init_from_env(backend="gloo")
-    torch.cuda.set_device(0)
+    ddp.init_from_env(backend=backend)
+    torch.cuda.set_device(local)
     m = _model()
     if rank == 1:                        # ranks start different; the trainer's broadcast must repair it
         with torch.no_grad():
@@ -56,12 +59,15 @@ def _worker(rank, world, port, out_path):
     torch.distributed.destroy_process_group()
 
 
-def test_two_ranks_match_single_process(tmp_path):
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_two_ranks_match_single_process(tmp_path, backend):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one GPU per rank: this box has a single GPU")
     from climate_amd.trainer import HotPathTrainer
     out_path = str(tmp_path / "rank0.pt")
-    mp.spawn(_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out_path, backend), nprocs=2, join=True)
     got = torch.load(out_path, weights_only=True)
     m = _model()
     tr = HotPathTrainer(m, lr=5e-4, use_graph=False, distributed=False)

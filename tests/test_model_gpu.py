@@ -202,39 +202,265 @@ def _se_margin(P, x):
 
 
 @pytest.mark.parametrize("shape", [
-    dict(base=64, T=3, B=2, H=48, W=72),        # BASELINE config 3's channel widths (base 64), short sequence
-    dict(base=16, T=2, B=1, H=192, W=288, grad_tol=3e-3),   # BASELINE config 5's upscaled grid (LDS-tile stress)
-    dict(base=64, T=2, B=1, H=96, W=144, grad_tol=1e-3),    # base 64 on a 2x grid (same near-tie caveat, 13 824 px)
+    dict(base=64, T=2, B=1, H=192, W=288),      # BASELINE config 5: base 64 on the 192x288 grid (one rank's kernels)
+    dict(base=64, T=12, B=2, H=48, W=72),       # BASELINE config 3: base 64, seq_len 12
+    dict(base=16, T=2, B=1, H=192, W=288),      # narrow channels on the wide grid (other tile / vector-width choices)
 ])
-def test_other_baseline_shapes_vs_oracle(amd, shape):
-    """Configs 3 and 5 of BASELINE.json are parity cases: same kernels, wider channels / larger grids, against the
-    CPU oracle on seeded inputs (sizes cut so the oracle finishes in seconds).
+def test_baseline_configs_3_and_5_vs_fp64_oracle(amd, shape):
+    """BASELINE.json configs 3 and 5 at their DEFINING channel widths, sequence length and grid (batch cut so the
+    fp64 oracle finishes in about a minute), every gradient at 1e-4.
 
-    The 192x288 case uses a looser GRADIENT tolerance (loss/output stay at 1e-5 / 1e-4): with 110 592 pixels per frame
-    the CBAM channel-max has near-ties (top-2 gap ~1e-7) at about one pixel per block, where ANY two fp32 evaluations
-    may pick different argmax channels; one flipped pixel moves the strongly cancelling SE gradient sums by ~0.5 %
-    (tools/debug_block.py decomposes exactly this: kernel sums equal the fp64 sum of their own inputs to 6e-7)."""
+    The loss gradient is discontinuous in the CBAM channel-argmax and the MaxPool argmax, and at these sizes some
+    pixel always sits on such a discontinuity (top-2 gap ~1e-7 relative: the best of 160 parameter / input draws had a
+    minimum amax gap of 2.9e-6, MaxPool windows ~1e-7), where two correct fp32 evaluations may choose differently.  So
+    the comparison is decision-aware (oracle.Decisions): the fp64 oracle's backward adopts the device path's choices
+    and VALIDATES each one -- the chosen element must lie within 1e-5 (relative) of the oracle's own maximum -- i.e.
+    the two may differ only where the reference function itself is ambiguous; a wrong choice is a failure
+    (``violations == 0``), and everything else is held to 1e-4 with no per-shape tolerance."""
+    from climate_amd import engine
+    from _decisions import hip_decisions
     in_ch, out_ch = 5, 2
     base, T, B, H, W = shape["base"], shape["T"], shape["B"], shape["H"], shape["W"]
     gen = torch.Generator("cpu").manual_seed(321)
     x = torch.randn(B, T, in_ch, H, W, generator=gen); y = torch.randn(B, out_ch, H, W, generator=gen)
     for salt in range(9, 30):
         P = oracle.closed_form_params(in_ch, out_ch, base, salt=salt)
-        if _se_margin(P, x) > 2e-3:
+        if _se_margin(P, x) > 2e-3:           # (a handful of SE hidden units per model: selectable, unlike pixels)
             break
     else:
         pytest.skip("no parameter set with a safe ReLU margin found")
-    pc = {k: v.clone().requires_grad_() for k, v in P.items()}
-    lc = oracle.training_loss(pc, x, y); lc.backward()
     m = _make(amd, in_ch, out_ch, base, T, salt=salt)
-    pred = m(x.cuda()); lg = F.mse_loss(pred, y.cuda()); lg.backward()
-    assert abs(lg.item() - lc.item()) < 1e-5 * abs(lc.item())
-    named = dict(m.named_parameters())
+    p = m._param_dict()
+    g = m._views(torch.zeros(m.n_flat_trainable, device="cuda"))
+    pk = engine.get_plan(p, None, False).pack()
+    pred, sv = engine.forward(p, pk, x.cuda(), save=True)
+    dec = hip_decisions(sv)
+    yd = y.cuda()
+    loss_hip = F.mse_loss(pred, yd).item()
+    engine.backward(p, pk, g, sv, (2.0 / pred.numel()) * (pred - yd))
+    torch.cuda.synchronize()
+    pc = {k: v.double().requires_grad_() for k, v in P.items()}
+    lc = oracle.training_loss(pc, x.double(), y.double(), decisions=dec); lc.backward()
+    print(f"{shape}: salt {salt}; {dec.sites} decision sites, {dec.differing} chosen differently from the oracle's own "
+          f"(all within 1e-5 of its maximum), violations {dec.violations}")
+    assert dec.violations == 0
+    assert dec.differing <= 1e-4 * dec.sites            # ambiguity is rare by construction
+    assert abs(loss_hip - lc.item()) < 1e-5 * abs(lc.item())
     worst = 0.0
     for k in pc:
         if pc[k].grad is not None:
-            e = rel_l2(named[k].grad, pc[k].grad)
+            e = rel_l2(g[k], pc[k].grad)
             worst = max(worst, e)
-            assert e < shape.get("grad_tol", TOL), (k, e)
-    assert rel_l2(pred, oracle.model_forward(P, x)) < TOL
+            assert e < TOL, (k, e)
+    with torch.no_grad():
+        assert rel_l2(pred, oracle.model_forward(P, x)) < TOL
     print(f"{shape}: worst grad rel-L2 {worst:.2e}")
+
+
+# ----------------------------------------------------------------------------------------------- full-size, fused path
+def _check_checksums(g, loss, grads, pred=None):
+    assert abs(loss - float(g["loss"])) < 1e-5 * float(g["loss"])
+    if pred is not None:
+        assert abs(pred.double().norm().item() - float(g["pred_l2"])) < 1e-5 * float(g["pred_l2"])
+        idx = torch.from_numpy(g["pred_sample_idx"])
+        assert rel_l2(pred.flatten().cpu()[idx], g["pred_samples"]) < TOL
+    for name, want, samp in zip(g["grad_names"].tolist(), g["grad_l2"].tolist(), g["grad_samples"]):
+        got = grads[name]
+        assert abs(got.double().norm().item() - want) <= TOL * want + 1e-12, name
+        ii = torch.linspace(0, got.numel() - 1, 8).long()
+        assert rel_l2(got.flatten().cpu()[ii], samp) < 5e-4, name
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_cfg2_full_size_through_the_benchmarked_trainer(amd, use_graph):
+    """The path bench.py times -- HotPathTrainer: batched pack / zero / unpack, fused head+MSE+head-backward, pruned
+    pack table, hipGraph replay -- at BASELINE config 2's full size against the reference's checksums: loss and every
+    gradient norm + samples after the first step (gradients stay in the flat buffer until the next step zeroes it)."""
+    from climate_amd.trainer import HotPathTrainer
+    g = load_golden("cfg2_checksums.npz")
+    in_ch, out_ch, base, T, B, H, W = (int(v) for v in g["cfg"])
+    m = _make(amd, in_ch, out_ch, base, T)
+    gen = torch.Generator("cpu").manual_seed(int(g["seed"]))
+    x = torch.randn(B, T, in_ch, H, W, generator=gen); y = torch.randn(B, out_ch, H, W, generator=gen)
+    tr = HotPathTrainer(m, lr=5e-4, use_graph=use_graph, distributed=False)
+    loss = tr.step(x.cuda(), y.cuda()).item()
+    _check_checksums(g, loss, m._views(tr.grad))
+    if use_graph:          # replaying the captured graph on the same batch: the loss goes down, gradients stay finite
+        l2 = tr.step(x.cuda(), y.cuda()).item()
+        assert l2 < loss and torch.isfinite(tr.grad).all()
+
+
+def test_default_init_left_padded_window(amd):
+    """The reference's real edge case end to end (main_final.py:76,127-131 + default init, beta = 0): every channel of
+    an all-zero frame is exactly 0 after GroupNorm+SiLU => C-way amax ties and all-equal MaxPool windows on WHOLE
+    frames.  Forward, loss, d(input) and all 73 gradients vs the reference fixture."""
+    from climate_amd.model import AttUNetConvLSTM
+    g = load_golden("model_default_init_padded.npz")
+    in_ch, out_ch, base, T = (int(v) for v in g["cfg"][:4])
+    m = AttUNetConvLSTM(in_ch, out_ch, base, T)
+    m.load_state_dict(_sub(g, "p."))
+    m = m.cuda()
+    x = g["x"].cuda().requires_grad_()
+    pred = m(x)
+    assert rel_l2(pred, g["pred"]) < TOL
+    loss = F.mse_loss(pred, g["y"].cuda())
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * float(g["loss"])
+    loss.backward()
+    assert rel_l2(x.grad, g["dx"]) < TOL
+    named = dict(m.named_parameters())
+    for k, want in _sub(g, "g.").items():
+        assert torch.isfinite(named[k].grad).all(), k
+        assert rel_l2(named[k].grad, want) < TOL, k
+
+
+def test_default_init_left_padded_window_cfg2_size(amd):
+    """Same edge case at BASELINE config 2's full size through the graphed trainer: seed-42 default init, 1/8 of the
+    samples with their first T-1 frames zeroed (SURVEY 8d second input set) vs the reference's checksums."""
+    from climate_amd.model import AttUNetConvLSTM
+    from climate_amd.trainer import HotPathTrainer
+    g = load_golden("cfg2_default_init_padded_checksums.npz")
+    in_ch, out_ch, base, T, B, H, W = (int(v) for v in g["cfg"])
+    torch.manual_seed(42)
+    m = AttUNetConvLSTM(in_ch, out_ch, base, T).cuda()
+    gen = torch.Generator("cpu").manual_seed(int(g["seed"]))
+    x = torch.randn(B, T, in_ch, H, W, generator=gen)
+    x[::8, :T - 1] = 0.0
+    y = torch.randn(B, out_ch, H, W, generator=gen)
+    with torch.no_grad():
+        pred = m(x.cuda())
+    tr = HotPathTrainer(m, lr=5e-4, use_graph=True, distributed=False)
+    loss = tr.step(x.cuda(), y.cuda()).item()
+    assert torch.isfinite(tr.grad).all()
+    _check_checksums(g, loss, m._views(tr.grad), pred)
+
+
+def test_plain_unet_vs_reference_fixture(amd):
+    """model.type = unet (src/unet.py:72-109) on the HIP engine vs the reference: forward, d(input), all 80 gradients."""
+    from climate_amd.model import UNet
+    g = load_golden("unet_tiny.npz")
+    in_ch, out_ch, base = (int(v) for v in g["cfg"][:3])
+    m = UNet(in_ch, out_ch, base)
+    m.load_state_dict(oracle.closed_form_params(in_ch, out_ch, base, salt=int(g["salt"]),
+                                                shapes=oracle.unet_param_shapes(in_ch, out_ch, base)))
+    m = m.cuda()
+    x = g["x"].cuda().requires_grad_()
+    pred = m(x)
+    assert rel_l2(pred, g["pred"]) < TOL
+    F.mse_loss(pred, g["y"].cuda()).backward()
+    assert rel_l2(x.grad, g["dx"]) < TOL
+    named = dict(m.named_parameters())
+    for k, want in _sub(g, "g.").items():
+        assert rel_l2(named[k].grad, want) < TOL, k
+
+
+# ----------------------------------------------------------------------------------------------- autograd contract
+def test_gradient_accumulation_and_two_calls_in_one_graph(amd):
+    """p.grad must not alias the engine's workspace: two micro-batches without zero_grad accumulate, and
+    two model calls inside one autograd graph both contribute -- against the oracle's gradients."""
+    in_ch, out_ch, base, T, B, H, W = 5, 2, 8, 3, 2, 16, 24
+    P = oracle.closed_form_params(in_ch, out_ch, base)
+    gen = torch.Generator("cpu").manual_seed(17)
+    xs = [torch.randn(B, T, in_ch, H, W, generator=gen) for _ in range(2)]
+    ys = [torch.randn(B, out_ch, H, W, generator=gen) for _ in range(2)]
+    pc = {k: v.clone().requires_grad_() for k, v in P.items()}
+    (oracle.training_loss(pc, xs[0], ys[0]) + 10.0 * oracle.training_loss(pc, xs[1], ys[1])).backward()
+    # (a) two backward passes, no zero_grad in between (Lightning accumulate_grad_batches = 2)
+    m = _make(amd, in_ch, out_ch, base, T)
+    F.mse_loss(m(xs[0].cuda()), ys[0].cuda()).backward()
+    (10.0 * F.mse_loss(m(xs[1].cuda()), ys[1].cuda())).backward()
+    named = dict(m.named_parameters())
+    for k in pc:
+        if pc[k].grad is not None:
+            assert rel_l2(named[k].grad, pc[k].grad) < TOL, ("accumulate", k)
+    # (b) zero_grad(set_to_none=False) keeps the tensors; the next backward must add into zeros, not into stale data
+    m.zero_grad(set_to_none=False)
+    F.mse_loss(m(xs[0].cuda()), ys[0].cuda()).backward()
+    pc0 = {k: v.clone().requires_grad_() for k, v in P.items()}
+    oracle.training_loss(pc0, xs[0], ys[0]).backward()
+    for k in pc0:
+        if pc0[k].grad is not None:
+            assert rel_l2(named[k].grad, pc0[k].grad) < TOL, ("zero_grad", k)
+    # (c) both calls in ONE graph
+    m2 = _make(amd, in_ch, out_ch, base, T)
+    (F.mse_loss(m2(xs[0].cuda()), ys[0].cuda()) + 10.0 * F.mse_loss(m2(xs[1].cuda()), ys[1].cuda())).backward()
+    named2 = dict(m2.named_parameters())
+    for k in pc:
+        if pc[k].grad is not None:
+            assert rel_l2(named2[k].grad, pc[k].grad) < TOL, ("one graph", k)
+
+
+def test_trainer_checkpoint_resume(amd):
+    """HotPathTrainer.state_dict()/load_state_dict(): a resumed run continues exactly like the uninterrupted one, and
+    the optimizer state is torch.optim.Adam's format (loads into torch.optim.Adam)."""
+    from climate_amd.trainer import HotPathTrainer
+    g = load_golden("model_tiny.npz")
+    in_ch, out_ch, base, T = (int(v) for v in g["cfg"][:4])
+    x, y = g["x"].cuda(), g["y"].cuda()
+    a = HotPathTrainer(_make(amd, in_ch, out_ch, base, T), lr=5e-4, use_graph=False)
+    for _ in range(2):
+        a.step(x, y)
+    ck = a.state_dict()
+    assert len(ck["optimizer"]["state"]) == 73 and float(ck["optimizer"]["state"][0]["step"]) == 2.0
+    l3 = a.step(x, y).item()
+    b = HotPathTrainer(_make(amd, in_ch, out_ch, base, T, salt=4), lr=1e-2, use_graph=True)
+    b.load_state_dict(ck)
+    assert b.lr == 5e-4
+    l3b = b.step(x, y).item()
+    assert abs(l3 - l3b) < 1e-6 * abs(l3)
+    assert abs(l3 - float(g["loss3"])) < 2e-5 * float(g["loss3"])
+    for k, want in _sub(g, "p3.").items():
+        assert rel_l2(b.model.state_dict()[k], want) < 1e-5, k
+    cpu = torch.optim.Adam([torch.nn.Parameter(v.cpu().clone()) for v in b.model.state_dict().values()], lr=1.0)
+    cpu.load_state_dict(b.optimizer_state_dict())
+    assert cpu.param_groups[0]["lr"] == 5e-4
+
+
+# ----------------------------------------------------------------------------------------------- determinism / overlap
+def test_run_twice_determinism(amd):
+    """Split-K convolutions and all weight gradients accumulate with fp32 atomics, so two runs are not bit-identical;
+    they must agree to rounding level (SURVEY section 5 asked for exactly this check), graph replay included."""
+    from climate_amd.trainer import HotPathTrainer
+    in_ch, out_ch, base, T, B, H, W = 5, 2, 32, 6, 32, 48, 72
+    m = _make(amd, in_ch, out_ch, base, T)
+    gen = torch.Generator("cpu").manual_seed(8)
+    x = torch.randn(B, T, in_ch, H, W, generator=gen).cuda(); y = torch.randn(B, out_ch, H, W, generator=gen).cuda()
+    tr = HotPathTrainer(m, lr=0.0, use_graph=False, distributed=False)     # lr = 0: parameters stay put
+    runs = []
+    for _ in range(3):
+        tr._fwd_bwd(x, y)
+        runs.append((tr.grad.clone(), tr.loss.item()))
+    tr.use_graph = True
+    tr.step(x, y)
+    runs.append((tr.grad.clone(), tr.loss.item()))
+    g0, l0 = runs[0]
+    lay = m._build_layout()
+    for gi, li in runs[1:]:
+        assert li == l0 or abs(li - l0) < 1e-7 * abs(l0)
+        for k, (o, n, _s) in lay.items():
+            if o + n <= g0.numel():
+                assert rel_l2(gi[o:o + n], g0[o:o + n]) < 2e-6, k
+
+
+def test_side_stream_overlap_eager_three_steps(amd, monkeypatch):
+    """CM_OVERLAP_WGRAD schedule (weight gradients on a second stream), EAGER, three steps at the benchmark size: the
+    configuration that produced non-finite gradients in round 1.  Finite, and equal to the serial schedule."""
+    from climate_amd import engine
+    from climate_amd.trainer import HotPathTrainer
+    in_ch, out_ch, base, T, B, H, W = 5, 2, 32, 6, 32, 48, 72
+    gen = torch.Generator("cpu").manual_seed(7)
+    x = torch.randn(B, T, in_ch, H, W, generator=gen).cuda()
+    y = (x[:, -1, :2] * 0.5 + x[:, 0, 1:3] * 0.25).contiguous()
+    res = {}
+    for overlap in (False, True):
+        monkeypatch.setattr(engine, "OVERLAP_WGRAD", overlap)
+        m = _make(amd, in_ch, out_ch, base, T)
+        tr = HotPathTrainer(m, lr=1e-3, use_graph=False, distributed=False)
+        losses = []
+        for _ in range(3):
+            losses.append(tr.step(x, y).item())
+            assert torch.isfinite(tr.grad).all(), (overlap, len(losses))
+        res[overlap] = (losses, {k: v.clone() for k, v in m.state_dict().items()})
+    for a, b in zip(*[res[k][0] for k in (False, True)]):
+        assert abs(a - b) < 1e-5 * abs(a)
+    for k in res[False][1]:
+        assert rel_l2(res[True][1][k], res[False][1][k]) < 1e-5, k
