@@ -202,8 +202,8 @@ def _se_margin(P, x):
 
 
 @pytest.mark.parametrize("shape", [
-    dict(base=64, T=2, B=1, H=192, W=288),      # BASELINE config 5: base 64 on the 192x288 grid (one rank's kernels)
-    dict(base=64, T=12, B=2, H=48, W=72),       # BASELINE config 3: base 64, seq_len 12
+    dict(base=64, T=6, B=1, H=192, W=288),      # BASELINE config 5: base 64, seq_len 6 on the 192x288 grid
+    dict(base=64, T=12, B=4, H=48, W=72),       # BASELINE config 3: base 64, seq_len 12
     dict(base=16, T=2, B=1, H=192, W=288),      # narrow channels on the wide grid (other tile / vector-width choices)
 ])
 def test_baseline_configs_3_and_5_vs_fp64_oracle(amd, shape):
