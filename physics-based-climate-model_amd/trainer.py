@@ -39,6 +39,8 @@ class HotPathTrainer:
         self._static = {}
         self._plans = []          # strong references: captured graphs hold raw pointers into these plans' arenas
         self.steps = 0
+        self.keep_saved = False   # debugging / tests: keep the last forward's saved activations in ``self.saved``
+        self.saved = None
 
     # ------------------------------------------------------------------ pieces
     def _fwd_bwd(self, x, y):
@@ -57,6 +59,8 @@ class HotPathTrainer:
         # output head + MSE + the head's backward: one pass over the last decoder activation
         dd1 = ops.head_mse_bwd(sv.d1, p["head.weight"], p["head.bias"], y, self.loss, g["head.weight"], g["head.bias"])
         self.model._engine_backward(p, pk, g, sv, None, need_dx=False, dd1=dd1)
+        if self.keep_saved:
+            self.saved = sv
 
     def _adam(self):
         b1, b2 = self.betas
