@@ -329,19 +329,31 @@ __global__ __launch_bounds__(256) void gate_bwd_reduce_kernel(const float* __res
   vec_t dg, k, mx;
 #pragma unroll
   for (int q = 0; q < VEC; ++q) { dg[q] = 0.f; k[q] = 0.f; mx[q] = -INFINITY; }
-#pragma unroll 8
-  for (int c = c0; c < c1; ++c) {
+  // one channel: running (max, multiplicity), branch-free -- a new maximum restarts the count at 1, an equal value adds 1
+  auto channel = [&](int c, float sc) {
     const long long i = ((long long)n * C + c) * HW + pp;
     const vec_t av = *reinterpret_cast<const vec_t*>(a2 + i), dv = *reinterpret_cast<const vec_t*>(dout + i);
-    const float sc = sp[c];
 #pragma unroll
     for (int q = 0; q < VEC; ++q) {
       const float u = av[q] * sc;
       dg[q] += dv[q] * u;
-      // running (max, multiplicity): a new maximum restarts the count at 1, an equal value adds 1
-      k[q] = (u > mx[q]) ? 1.f : (u == mx[q] ? k[q] + 1.f : k[q]);
+      const float same = (u == mx[q]) ? 1.f : 0.f;
+      k[q] = (u > mx[q]) ? 1.f : k[q] + same;
       mx[q] = fmaxf(mx[q], u);
     }
+  };
+  if (((cper | C) & 3) == 0) {
+    // the wave's channel range is a multiple of four: the SE scales come as 16-byte (uniform-address) loads
+    for (int c = c0; c < c1; c += 4) {
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(sp + c);
+      channel(c, s4.x);
+      channel(c + 1, s4.y);
+      channel(c + 2, s4.z);
+      channel(c + 3, s4.w);
+    }
+  } else {
+#pragma unroll 4
+    for (int c = c0; c < c1; ++c) channel(c, sp[c]);
   }
 #pragma unroll
   for (int q = 0; q < VEC; ++q) {
