@@ -471,7 +471,7 @@ def test_run_twice_determinism(amd):
     g0, l0 = runs[0]
     lay = m._build_layout()
     for gi, li in runs[1:]:
-        assert li == l0 or abs(li - l0) < 1e-7 * abs(l0)
+        assert abs(li - l0) < 1e-6 * abs(l0)                   # (the loss is summed with float atomics: +-1 ulp)
         for k, (o, n, _s) in lay.items():
             if o + n <= g0.numel():
                 assert rel_l2(gi[o:o + n], g0[o:o + n]) < 1e-5, k       # (observed <= 2.5e-6: cancelling GroupNorm sums)
