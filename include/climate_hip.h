@@ -61,6 +61,13 @@ int cm_conv3x3_split(const float* in0, long long st0, int c0, const float* in1, 
                      const void* wps, const float* bias, const float* resid, long long st_resid, float* out,
                      long long st_out, int n, int h, int w, int cout, int config, cm_stream stream);
 
+/* EXPERIMENTAL fp16x3 form (two fp16 pieces per operand, three products, power-of-two operand scales); see
+ * csrc/split_f16.h.  Packed weights: 2/3 of cm_conv3x3_split_packed_bytes(). */
+int cm_pack_conv3x3_h3_batch(const void* descs_dev, int ndesc, int total_blocks, float wscale, cm_stream stream);
+int cm_conv3x3_h3(const float* in0, long long st0, int c0, const float* in1, long long st1, int c1, const void* wps,
+                  const float* bias, const float* resid, long long st_resid, float* out, long long st_out, int n, int h,
+                  int w, int cout, int config, float xscale, float oscale, cm_stream stream);
+
 /* Forward conv for VERY FEW input channels (cin * 9 <= 64; the first layer, src/unet.py:36 at
  * src/unet_convlstm_attention.py:35): the reduction index is the (input channel, tap) pair, fp32 MFMA, weights read
  * UNPACKED ([cout][cin][3][3]).  out = conv(x, w) + bias.  w_ <= 320. */

@@ -18,6 +18,7 @@
 //     bandwidth and 24-48 VGPRs of ping-pong registers).
 #include "common.h"
 #include "split_bf16.h"
+#include "split_f16.h"
 #include "../../include/climate_hip.h"
 
 namespace {
@@ -38,6 +39,7 @@ struct SplitArgs {
   int dbg;     // diagnostic ablation bits (CM_CONVS_DBG): 1 skip global loads, 2 skip MFMA phase, 8 skip convert+store
   int ksplit;  // > 1: blockIdx.z owns a share of the k-steps and accumulates into a pre-zeroed output with atomics
   int prezeroed;   // the caller already zeroed `out` (one fill for several launches): skip the internal zero launch
+  float xscale, oscale;   // fp16x3: power-of-two input scale and 1 / (input scale * weight scale)
 };
 
 // Workgroups with one 32x32 tile per wave sit 2 registers above the 3-waves-per-SIMD allocation (170 of 168): ask for
@@ -45,7 +47,8 @@ struct SplitArgs {
 // them; LDS allows three 4-wave workgroups per CU (<= 53 KB each).
 constexpr int split_min_waves(int waves, int npt, int wm) { return (npt * wm == 1 && waves == 4) ? 3 : 1; }
 
-template <int TH, int TW, int S, int WAVES, int NPT, int WM, bool DUAL>
+// NP = 3: bf16x6 (three bf16 pieces, six products); NP = 2: fp16x3 (two fp16 pieces, three products; split_f16.h)
+template <int TH, int TW, int S, int WAVES, int NPT, int WM, bool DUAL, int NP>
 __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void conv3x3_split_kernel(SplitArgs a) {
   constexpr int THREADS = WAVES * 64;
   constexpr int PITCH = TW + 2;
@@ -54,12 +57,12 @@ __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void c
   constexpr int ITEMS = PH * 2;                  // (pixel, channel octet) records per 16-channel stage
   constexpr int NI = (ITEMS + THREADS - 1) / THREADS;
   constexpr int BCO = 32 * WM;
-  constexpr int WREC = 3 * 9 * 2 * BCO;          // weight records (16 B) per stage
+  constexpr int WREC = NP * 9 * 2 * BCO;         // weight records (16 B) per stage
   constexpr int NWR = (WREC + THREADS - 1) / THREADS;
   constexpr int PIX = S * TH * TW;
   static_assert(WAVES * NPT * 32 >= PIX, "block does not cover its pixel set");
 
-  __shared__ u32x4 Xl[3 * 2 * PH];               // [piece][octet][pixel]
+  __shared__ u32x4 Xl[NP * 2 * PH];              // [piece][octet][pixel]
   __shared__ u32x4 Wl[WREC];                     // [piece][tap][octet][cout]
 
   const int tid = threadIdx.x;
@@ -150,14 +153,17 @@ __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void c
       for (int q = 0; q < 4; ++q) {
         const bool ok0 = goff0[i] >= 0 && (oct * 8 + 2 * q) < cvalid_pending;
         const bool ok1 = goff0[i] >= 0 && (oct * 8 + 2 * q + 1) < cvalid_pending;
-        unsigned a_, b_, c_;
-        split3_pair(ok0 ? xr[i][2 * q] : 0.f, ok1 ? xr[i][2 * q + 1] : 0.f, a_, b_, c_);
+        unsigned a_, b_, c_ = 0;
+        if constexpr (NP == 3)
+          split3_pair(ok0 ? xr[i][2 * q] : 0.f, ok1 ? xr[i][2 * q + 1] : 0.f, a_, b_, c_);
+        else
+          split2_pair_f16(ok0 ? xr[i][2 * q] * a.xscale : 0.f, ok1 ? xr[i][2 * q + 1] * a.xscale : 0.f, a_, b_);
         ph[q] = a_; pm[q] = b_; pl[q] = c_;
       }
       if (e < ITEMS) {
         Xl[(0 * 2 + oct) * PH + pix] = ph;
         Xl[(1 * 2 + oct) * PH + pix] = pm;
-        Xl[(2 * 2 + oct) * PH + pix] = pl;
+        if constexpr (NP == 3) Xl[(2 * 2 + oct) * PH + pix] = pl;
       }
     }
 #pragma unroll
@@ -205,27 +211,49 @@ __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void c
     if (!(a.dbg & 2))
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      bf16x8 bf[3][NPT];
-#pragma unroll
-      for (int pc = 0; pc < 3; ++pc)
-#pragma unroll
-        for (int p = 0; p < NPT; ++p)
-          bf[pc][p] = __builtin_bit_cast(bf16x8, Xl[(pc * 2) * PH + xbase[p] + (tap / 3) * PITCH + (tap % 3)]);
-#pragma unroll
-      for (int m = 0; m < WM; ++m) {
-        bf16x8 af[3];
+      if constexpr (NP == 3) {
+        bf16x8 bf[3][NPT];
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc)
-          af[pc] = __builtin_bit_cast(bf16x8, Wl[(pc * 9 + tap) * 2 * BCO + wlane + m * 32]);
 #pragma unroll
-        for (int p = 0; p < NPT; ++p) {
-          // smallest terms first
-          acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1][p], acc[m][p], 0, 0, 0);
-          acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0][p], acc[m][p], 0, 0, 0);
-          acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2][p], acc[m][p], 0, 0, 0);
-          acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0][p], acc[m][p], 0, 0, 0);
-          acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1][p], acc[m][p], 0, 0, 0);
-          acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0][p], acc[m][p], 0, 0, 0);
+          for (int p = 0; p < NPT; ++p)
+            bf[pc][p] = __builtin_bit_cast(bf16x8, Xl[(pc * 2) * PH + xbase[p] + (tap / 3) * PITCH + (tap % 3)]);
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+          bf16x8 af[3];
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc)
+            af[pc] = __builtin_bit_cast(bf16x8, Wl[(pc * 9 + tap) * 2 * BCO + wlane + m * 32]);
+#pragma unroll
+          for (int p = 0; p < NPT; ++p) {
+            // smallest terms first
+            acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1][p], acc[m][p], 0, 0, 0);
+            acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0][p], acc[m][p], 0, 0, 0);
+            acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2][p], acc[m][p], 0, 0, 0);
+            acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0][p], acc[m][p], 0, 0, 0);
+            acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1][p], acc[m][p], 0, 0, 0);
+            acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0][p], acc[m][p], 0, 0, 0);
+          }
+        }
+      } else {
+        f16x8 bf[2][NPT];
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+          for (int p = 0; p < NPT; ++p)
+            bf[pc][p] = __builtin_bit_cast(f16x8, Xl[(pc * 2) * PH + xbase[p] + (tap / 3) * PITCH + (tap % 3)]);
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+          f16x8 af[2];
+#pragma unroll
+          for (int pc = 0; pc < 2; ++pc)
+            af[pc] = __builtin_bit_cast(f16x8, Wl[(pc * 9 + tap) * 2 * BCO + wlane + m * 32]);
+#pragma unroll
+          for (int p = 0; p < NPT; ++p) {
+            acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1], bf[0][p], acc[m][p], 0, 0, 0);
+            acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[1][p], acc[m][p], 0, 0, 0);
+            acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[0][p], acc[m][p], 0, 0, 0);
+          }
         }
       }
     }
@@ -233,6 +261,14 @@ __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void c
   }
 
   // ---- epilogue (same accumulator map as the fp32 kernel) ----
+  if constexpr (NP == 2) {
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+      for (int p = 0; p < NPT; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][p][r] *= a.oscale;
+  }
   if (a.bias && blockIdx.z == 0) {
 #pragma unroll
     for (int m = 0; m < WM; ++m) {
@@ -286,7 +322,8 @@ __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void c
 // ------------------------------------------------------------------------------------------------ packer
 // descs as cm_pack_conv3x3_batch: {w ptr, wps ptr, cout, cin_total, c_off, cin, dgrad, first block}
 // output record (piece, T = step*9 + tap, octet-half h, col) = 8 bf16 pieces of k-channels step*16 + h*8 + j
-__global__ void pack_split_batch_kernel(const long long* __restrict__ descs, int ndesc) {
+template <int NP>
+__global__ void pack_split_batch_kernel(const long long* __restrict__ descs, int ndesc, float wscale) {
   int d = 0;
   while (d + 1 < ndesc && descs[(d + 1) * 8 + 7] <= (long long)blockIdx.x) ++d;
   const long long* r = descs + d * 8;
@@ -318,13 +355,14 @@ __global__ void pack_split_batch_kernel(const long long* __restrict__ descs, int
     u32x4 ph, pm, pl;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      unsigned a_, b_, c_;
-      split3_pair(vv[2 * q], vv[2 * q + 1], a_, b_, c_);
+      unsigned a_, b_, c_ = 0;
+      if constexpr (NP == 3) split3_pair(vv[2 * q], vv[2 * q + 1], a_, b_, c_);
+      else split2_pair_f16(vv[2 * q] * wscale, vv[2 * q + 1] * wscale, a_, b_);
       ph[q] = a_; pm[q] = b_; pl[q] = c_;
     }
     wps[i] = ph;
     wps[recs + i] = pm;
-    wps[2 * recs + i] = pl;
+    if constexpr (NP == 3) wps[2 * recs + i] = pl;
   }
 }
 
@@ -371,7 +409,7 @@ __global__ void zero_out_split_kernel(float* __restrict__ out, long long sto, in
     out[(i / per) * sto + i % per] = 0.f;
 }
 
-template <int I, bool DUAL>
+template <int I, bool DUAL, int NP>
 int launch_s(const SplitArgs& a0, hipStream_t st) {
   constexpr SCfg c = kS[I];
   SplitArgs a = a0;
@@ -385,42 +423,42 @@ int launch_s(const SplitArgs& a0, hipStream_t st) {
     zero_out_split_kernel<<<(int)(zb > 2048 ? 2048 : zb), 256, 0, st>>>(a.out, a.sto, a.N, per);
   }
   dim3 grid(a.tiles_x * a.tiles_y * cdiv(a.N, c.s), cdiv(a.Cout, 32 * c.wm), a.ksplit);
-  conv3x3_split_kernel<c.th, c.tw, c.s, c.waves, c.npt, c.wm, DUAL><<<grid, c.waves * 64, 0, st>>>(a);
+  conv3x3_split_kernel<c.th, c.tw, c.s, c.waves, c.npt, c.wm, DUAL, NP><<<grid, c.waves * 64, 0, st>>>(a);
   CM_CHECK_LAUNCH();
   return 0;
 }
 
-template <bool DUAL>
+template <bool DUAL, int NP>
 int dispatch_s(int cfg, const SplitArgs& a, hipStream_t st) {
   switch (cfg) {
-    case 0: return launch_s<0, DUAL>(a, st);
-    case 1: return launch_s<1, DUAL>(a, st);
-    case 2: return launch_s<2, DUAL>(a, st);
-    case 3: return launch_s<3, DUAL>(a, st);
-    case 4: return launch_s<4, DUAL>(a, st);
-    case 5: return launch_s<5, DUAL>(a, st);
-    case 6: return launch_s<6, DUAL>(a, st);
-    case 7: return launch_s<7, DUAL>(a, st);
-    case 8: return launch_s<8, DUAL>(a, st);
-    case 9: return launch_s<9, DUAL>(a, st);
-    case 10: return launch_s<10, DUAL>(a, st);
-    case 11: return launch_s<11, DUAL>(a, st);
-    case 12: return launch_s<12, DUAL>(a, st);
-    case 13: return launch_s<13, DUAL>(a, st);
-    case 14: return launch_s<14, DUAL>(a, st);
-    case 15: return launch_s<15, DUAL>(a, st);
-    case 16: return launch_s<16, DUAL>(a, st);
-    case 17: return launch_s<17, DUAL>(a, st);
-    case 18: return launch_s<18, DUAL>(a, st);
-    case 19: return launch_s<19, DUAL>(a, st);
-    case 20: return launch_s<20, DUAL>(a, st);
-    case 21: return launch_s<21, DUAL>(a, st);
-    case 22: return launch_s<22, DUAL>(a, st);
-    case 23: return launch_s<23, DUAL>(a, st);
-    case 24: return launch_s<24, DUAL>(a, st);
-    case 25: return launch_s<25, DUAL>(a, st);
-    case 26: return launch_s<26, DUAL>(a, st);
-    case 27: return launch_s<27, DUAL>(a, st);
+    case 0: return launch_s<0, DUAL, NP>(a, st);
+    case 1: return launch_s<1, DUAL, NP>(a, st);
+    case 2: return launch_s<2, DUAL, NP>(a, st);
+    case 3: return launch_s<3, DUAL, NP>(a, st);
+    case 4: return launch_s<4, DUAL, NP>(a, st);
+    case 5: return launch_s<5, DUAL, NP>(a, st);
+    case 6: return launch_s<6, DUAL, NP>(a, st);
+    case 7: return launch_s<7, DUAL, NP>(a, st);
+    case 8: return launch_s<8, DUAL, NP>(a, st);
+    case 9: return launch_s<9, DUAL, NP>(a, st);
+    case 10: return launch_s<10, DUAL, NP>(a, st);
+    case 11: return launch_s<11, DUAL, NP>(a, st);
+    case 12: return launch_s<12, DUAL, NP>(a, st);
+    case 13: return launch_s<13, DUAL, NP>(a, st);
+    case 14: return launch_s<14, DUAL, NP>(a, st);
+    case 15: return launch_s<15, DUAL, NP>(a, st);
+    case 16: return launch_s<16, DUAL, NP>(a, st);
+    case 17: return launch_s<17, DUAL, NP>(a, st);
+    case 18: return launch_s<18, DUAL, NP>(a, st);
+    case 19: return launch_s<19, DUAL, NP>(a, st);
+    case 20: return launch_s<20, DUAL, NP>(a, st);
+    case 21: return launch_s<21, DUAL, NP>(a, st);
+    case 22: return launch_s<22, DUAL, NP>(a, st);
+    case 23: return launch_s<23, DUAL, NP>(a, st);
+    case 24: return launch_s<24, DUAL, NP>(a, st);
+    case 25: return launch_s<25, DUAL, NP>(a, st);
+    case 26: return launch_s<26, DUAL, NP>(a, st);
+    case 27: return launch_s<27, DUAL, NP>(a, st);
     default: return -22;
   }
 }
@@ -439,7 +477,15 @@ long long cm_conv3x3_split_packed_bytes(int k_channels, int out_channels) {
 
 int cm_pack_conv3x3_split_batch(const void* descs_dev, int ndesc, int total_blocks, cm_stream stream) {
   if (ndesc <= 0 || total_blocks <= 0) return -22;
-  pack_split_batch_kernel<<<total_blocks, 256, 0, (hipStream_t)stream>>>((const long long*)descs_dev, ndesc);
+  pack_split_batch_kernel<3><<<total_blocks, 256, 0, (hipStream_t)stream>>>((const long long*)descs_dev, ndesc, 1.f);
+  CM_CHECK_LAUNCH();
+  return 0;
+}
+
+/* EXPERIMENT (fp16x3): same descriptor records, two fp16 pieces per weight scaled by `wscale` (a power of two). */
+int cm_pack_conv3x3_h3_batch(const void* descs_dev, int ndesc, int total_blocks, float wscale, cm_stream stream) {
+  if (ndesc <= 0 || total_blocks <= 0) return -22;
+  pack_split_batch_kernel<2><<<total_blocks, 256, 0, (hipStream_t)stream>>>((const long long*)descs_dev, ndesc, wscale);
   CM_CHECK_LAUNCH();
   return 0;
 }
@@ -464,7 +510,30 @@ int cm_conv3x3_split(const float* in0, long long st0, int c0, const float* in1, 
   config &= 0xff;
   if (a.ksplit > 1 && resid == out) return -22;   // the in-place residual would be zeroed
   a.tiles_x = a.tiles_y = 0;
-  return c1 > 0 ? dispatch_s<true>(config, a, (hipStream_t)stream) : dispatch_s<false>(config, a, (hipStream_t)stream);
+  a.xscale = a.oscale = 1.f;
+  return c1 > 0 ? dispatch_s<true, 3>(config, a, (hipStream_t)stream) : dispatch_s<false, 3>(config, a, (hipStream_t)stream);
+}
+
+/* EXPERIMENT (fp16x3): cm_conv3x3_split with two fp16 pieces / three products.  wps from cm_pack_conv3x3_h3_batch;
+ * xscale: power of two applied to the input before the split; oscale = 1 / (xscale * wscale). */
+int cm_conv3x3_h3(const float* in0, long long st0, int c0, const float* in1, long long st1, int c1, const void* wps,
+                  const float* bias, const float* resid, long long st_resid, float* out, long long st_out, int n, int h,
+                  int w, int cout, int config, float xscale, float oscale, cm_stream stream) {
+  if (n <= 0 || h <= 0 || w <= 0 || cout <= 0 || c0 <= 0 || c1 < 0 || config < 0) return -22;
+  if (c1 > 0 && (c0 % SKC) != 0) return -22;
+  if (resid && st_resid != st_out) return -22;
+  if (bias || resid) return -22;             // (experiment: plain conv only)
+  SplitArgs a;
+  a.in0 = in0; a.in1 = in1; a.st0 = st0; a.st1 = st1; a.C0 = c0; a.C1 = c1;
+  a.wps = (const u32x4*)wps; a.bias = bias; a.resid = resid; a.out = out; a.sto = st_out;
+  a.N = n; a.H = h; a.W = w; a.Cout = cout;
+  a.CoutP = ((cout + 31) / 32) * 32;
+  a.nsteps = (c0 + c1 + SKC - 1) / SKC;
+  a.dbg = 0; a.prezeroed = 0; a.ksplit = 1;
+  config &= 0xff;
+  a.tiles_x = a.tiles_y = 0;
+  a.xscale = xscale; a.oscale = oscale;
+  return c1 > 0 ? dispatch_s<true, 2>(config, a, (hipStream_t)stream) : dispatch_s<false, 2>(config, a, (hipStream_t)stream);
 }
 
 }  // extern "C"
