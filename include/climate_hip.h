@@ -61,12 +61,19 @@ int cm_conv3x3_split(const float* in0, long long st0, int c0, const float* in1, 
                      const void* wps, const float* bias, const float* resid, long long st_resid, float* out,
                      long long st_out, int n, int h, int w, int cout, int config, cm_stream stream);
 
-/* EXPERIMENTAL fp16x3 form (two fp16 pieces per operand, three products, power-of-two operand scales); see
- * csrc/split_f16.h.  Packed weights: 2/3 of cm_conv3x3_split_packed_bytes(). */
-int cm_pack_conv3x3_h3_batch(const void* descs_dev, int ndesc, int total_blocks, float wscale, cm_stream stream);
+/* ---- conv3x3 on the f16 matrix cores with fp32-equivalent accuracy ("fp16x3") -------------------------------------- *
+ * Same contract, reference call sites and config encoding as cm_conv3x3_split, half its matrix work: every operand is
+ * split into TWO fp16 pieces (22 mantissa bits), three products hi*hi + hi*lo + lo*hi, fp32 accumulation (measured
+ * 2e-7..5e-7 relative, the level of an fp32 convolution).  fp16's 5 exponent bits are handled by exact power-of-two
+ * scaling: the weights per packed slice (cm_pack_conv3x3_h3_batch measures max |w|), the input per workgroup from the
+ * running maximum of what it has staged (no history, no calibration, any magnitude; inf / NaN propagate).
+ * cm_pack_conv3x3_h3_batch: descriptor records as cm_pack_conv3x3_batch with the wp field pointing at
+ * cm_conv3x3_h3_packed_bytes() bytes; scratch = 2 * ndesc floats; scratch[ndesc + job] is that job's wscale_inv.     */
+long long cm_conv3x3_h3_packed_bytes(int k_channels, int out_channels);
+int cm_pack_conv3x3_h3_batch(const void* descs_dev, int ndesc, int total_blocks, float* scratch, cm_stream stream);
 int cm_conv3x3_h3(const float* in0, long long st0, int c0, const float* in1, long long st1, int c1, const void* wps,
-                  const float* bias, const float* resid, long long st_resid, float* out, long long st_out, int n, int h,
-                  int w, int cout, int config, float xscale, float oscale, cm_stream stream);
+                  const float* wscale_inv, const float* bias, const float* resid, long long st_resid, float* out,
+                  long long st_out, int n, int h, int w, int cout, int config, cm_stream stream);
 
 /* Forward conv for VERY FEW input channels (cin * 9 <= 64; the first layer, src/unet.py:36 at
  * src/unet_convlstm_attention.py:35): the reduction index is the (input channel, tap) pair, fp32 MFMA, weights read

@@ -39,7 +39,7 @@ struct SplitArgs {
   int dbg;     // diagnostic ablation bits (CM_CONVS_DBG): 1 skip global loads, 2 skip MFMA phase, 8 skip convert+store
   int ksplit;  // > 1: blockIdx.z owns a share of the k-steps and accumulates into a pre-zeroed output with atomics
   int prezeroed;   // the caller already zeroed `out` (one fill for several launches): skip the internal zero launch
-  float xscale, oscale;   // fp16x3: power-of-two input scale and 1 / (input scale * weight scale)
+  const float* winv;      // fp16x3: device scalar, 1 / (power-of-two scale the packed weights carry)
 };
 
 // Workgroups with one 32x32 tile per wave sit 2 registers above the 3-waves-per-SIMD allocation (170 of 168): ask for
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void c
       wr[i] = wsrc[pc * piece_stride + (long long)th * a_CoutP + col];
     }
   };
-  auto store_chunk = [&]() {
+  auto store_chunk = [&](float xsc) {
     if (a.dbg & 8) return;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void c
         if constexpr (NP == 3)
           split3_pair(ok0 ? xr[i][2 * q] : 0.f, ok1 ? xr[i][2 * q + 1] : 0.f, a_, b_, c_);
         else
-          split2_pair_f16(ok0 ? xr[i][2 * q] * a.xscale : 0.f, ok1 ? xr[i][2 * q + 1] * a.xscale : 0.f, a_, b_);
+          split2_pair_f16(ok0 ? xr[i][2 * q] * xsc : 0.f, ok1 ? xr[i][2 * q + 1] * xsc : 0.f, a_, b_);
         ph[q] = a_; pm[q] = b_; pl[q] = c_;
       }
       if (e < ITEMS) {
@@ -203,9 +203,57 @@ __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void c
   const int cps = (nsteps + a.ksplit - 1) / a.ksplit;
   const int c_begin = blockIdx.z * cps, c_end = min(nsteps, c_begin + cps);
   if (c_begin >= c_end) return;
+  // fp16x3: the staged tile of every 16-channel stage is scaled by a power of two chosen from the RUNNING maximum of
+  // |x| over everything this workgroup has staged so far (exact: no history, no calibration, any input range).  Each
+  // wave posts the maximum of the registers it just loaded before the barrier that ends a stage; after it every thread
+  // combines the posts.  The scale can only shrink; when it does, the accumulators (which carry the scale) follow.
+  __shared__ float smax[2][WAVES];
+  unsigned be_cur = 0;                    // biased exponent of the running maximum (0 = nothing but zeros yet)
+  auto post_max = [&](int buf) {
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int oct = (tid + i * THREADS) / PH;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool live = goff0[i] >= 0 && oct * 8 + j < cvalid_pending;     // exactly what store_chunk keeps
+        m = fmaxf(m, live ? fabsf(xr[i][j]) : 0.f);
+      }
+    }
+    m = wave_max(m);
+    if (lane == 0) smax[buf][wave] = m;
+  };
+  // scale 2^(140 - be): the running maximum lands in [2^13, 2^14); its inverse 2^(be - 140)
+  auto scale_of = [&](unsigned be) { return __uint_as_float((267u - max(be, 13u)) << 23); };
   load_chunk(c_begin);
+  if constexpr (NP == 2) {
+    post_max(0);
+    __syncthreads();
+  }
   for (int chunk = c_begin; chunk < c_end; ++chunk) {
-    store_chunk();
+    float xsc = 1.f;
+    if constexpr (NP == 2) {
+      const int buf = (chunk - c_begin) & 1;
+      float m = 0.f;
+#pragma unroll
+      for (int w_ = 0; w_ < WAVES; ++w_) m = fmaxf(m, smax[buf][w_]);
+      const unsigned be = max(be_cur, (__float_as_uint(m) >> 23) & 0xffu);     // (NaN / inf: be = 255, propagates)
+      if (be != be_cur) {
+        if (be_cur != 0) {                // accumulators hold sums at the old scale: bring them to the new one
+          const int d = (int)be - (int)be_cur;
+          const float f = d > 126 ? 0.f : __uint_as_float((unsigned)(127 - d) << 23);
+#pragma unroll
+          for (int m_ = 0; m_ < WM; ++m_)
+#pragma unroll
+            for (int p = 0; p < NPT; ++p)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[m_][p][r] *= f;
+        }
+        be_cur = be;
+      }
+      xsc = scale_of(be_cur);
+    }
+    store_chunk(xsc);
     __syncthreads();
     if (chunk + 1 < c_end) load_chunk(chunk + 1);
     if (!(a.dbg & 2))
@@ -257,17 +305,23 @@ __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void c
         }
       }
     }
+    if constexpr (NP == 2) {
+      if (chunk + 1 < c_end) post_max(((chunk - c_begin) & 1) ^ 1);
+    }
     __syncthreads();
   }
 
   // ---- epilogue (same accumulator map as the fp32 kernel) ----
   if constexpr (NP == 2) {
+    // undo the operand scales: 2^(be - 140) for the input (0 if nothing but zeros was staged), *winv for the weights
+    const float xinv = be_cur <= 13u ? 0.f : __uint_as_float((be_cur - 13u) << 23);
+    const float winv = a.winv[0];
 #pragma unroll
     for (int m = 0; m < WM; ++m)
 #pragma unroll
       for (int p = 0; p < NPT; ++p)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][p][r] *= a.oscale;
+        for (int r = 0; r < 16; ++r) acc[m][p][r] = (acc[m][p][r] * xinv) * winv;
   }
   if (a.bias && blockIdx.z == 0) {
 #pragma unroll
@@ -322,8 +376,27 @@ __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void c
 // ------------------------------------------------------------------------------------------------ packer
 // descs as cm_pack_conv3x3_batch: {w ptr, wps ptr, cout, cin_total, c_off, cin, dgrad, first block}
 // output record (piece, T = step*9 + tap, octet-half h, col) = 8 bf16 pieces of k-channels step*16 + h*8 + j
+// per-job max |w| over the slice the job packs (uint compare of non-negative float bits): scratch[d], zeroed before
+__global__ void weight_amax_batch_kernel(const long long* __restrict__ descs, int ndesc, unsigned* __restrict__ amax) {
+  int d = 0;
+  while (d + 1 < ndesc && descs[(d + 1) * 8 + 7] <= (long long)blockIdx.x) ++d;
+  const long long* r = descs + d * 8;
+  const float* w = reinterpret_cast<const float*>(r[0]);
+  const int cout = (int)r[2], cin_total = (int)r[3], c_off = (int)r[4], cin = (int)r[5];
+  const int b0 = (int)r[7], nb = (int)descs[(d + 1) * 8 + 7] - b0;
+  const long long total = (long long)cout * cin * 9;
+  float m = 0.f;
+  for (long long i = (long long)(blockIdx.x - b0) * blockDim.x + threadIdx.x; i < total; i += (long long)nb * blockDim.x) {
+    const long long row = i / (cin * 9), rem = i % (cin * 9);
+    m = fmaxf(m, fabsf(w[(row * cin_total + c_off) * 9 + rem]));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(amax + d, __float_as_uint(m));
+}
+
 template <int NP>
-__global__ void pack_split_batch_kernel(const long long* __restrict__ descs, int ndesc, float wscale) {
+__global__ void pack_split_batch_kernel(const long long* __restrict__ descs, int ndesc, const unsigned* __restrict__ amax,
+                                        float* __restrict__ winv_out) {
   int d = 0;
   while (d + 1 < ndesc && descs[(d + 1) * 8 + 7] <= (long long)blockIdx.x) ++d;
   const long long* r = descs + d * 8;
@@ -334,6 +407,12 @@ __global__ void pack_split_batch_kernel(const long long* __restrict__ descs, int
   const int kch = dgrad ? cout : cin, ocs = dgrad ? cin : cout;
   const int nsteps = (kch + SKC - 1) / SKC, colsP = ((ocs + 31) / 32) * 32;
   const long long recs = (long long)nsteps * 9 * 2 * colsP;      // records per piece
+  float wscale = 1.f;
+  if constexpr (NP == 2) {              // largest weight -> [2^13, 2^14); the conv's epilogue multiplies by winv
+    const unsigned be = max((amax[d] >> 23) & 0xffu, 13u);
+    wscale = __uint_as_float((267u - be) << 23);
+    if (blockIdx.x == b0 && threadIdx.x == 0) winv_out[d] = be <= 13u ? 0.f : __uint_as_float((be - 13u) << 23);
+  }
   for (long long i = (long long)(blockIdx.x - b0) * blockDim.x + threadIdx.x; i < recs; i += (long long)nb * blockDim.x) {
     const int col = (int)(i % colsP);
     long long t = i / colsP;
@@ -477,17 +556,28 @@ long long cm_conv3x3_split_packed_bytes(int k_channels, int out_channels) {
 
 int cm_pack_conv3x3_split_batch(const void* descs_dev, int ndesc, int total_blocks, cm_stream stream) {
   if (ndesc <= 0 || total_blocks <= 0) return -22;
-  pack_split_batch_kernel<3><<<total_blocks, 256, 0, (hipStream_t)stream>>>((const long long*)descs_dev, ndesc, 1.f);
+  pack_split_batch_kernel<3><<<total_blocks, 256, 0, (hipStream_t)stream>>>((const long long*)descs_dev, ndesc, nullptr,
+                                                                            nullptr);
   CM_CHECK_LAUNCH();
   return 0;
 }
 
-/* EXPERIMENT (fp16x3): same descriptor records, two fp16 pieces per weight scaled by `wscale` (a power of two). */
-int cm_pack_conv3x3_h3_batch(const void* descs_dev, int ndesc, int total_blocks, float wscale, cm_stream stream) {
-  if (ndesc <= 0 || total_blocks <= 0) return -22;
-  pack_split_batch_kernel<2><<<total_blocks, 256, 0, (hipStream_t)stream>>>((const long long*)descs_dev, ndesc, wscale);
+/* fp16x3 operand form: same descriptor records as cm_pack_conv3x3_split_batch; every job's weight slice is scaled by
+ * its own power of two (largest |w| -> [2^13, 2^14)) and split into two fp16 pieces.  scratch: 2*ndesc floats,
+ * [0, ndesc) = workspace, [ndesc, 2*ndesc) = per-job inverse scales (pass &scratch[ndesc + job] to cm_conv3x3_h3). */
+int cm_pack_conv3x3_h3_batch(const void* descs_dev, int ndesc, int total_blocks, float* scratch, cm_stream stream) {
+  if (ndesc <= 0 || total_blocks <= 0 || !scratch) return -22;
+  hipStream_t st = (hipStream_t)stream;
+  zero_out_split_kernel<<<1, 256, 0, st>>>(scratch, 0, 1, ndesc);
+  weight_amax_batch_kernel<<<total_blocks, 256, 0, st>>>((const long long*)descs_dev, ndesc, (unsigned*)scratch);
+  pack_split_batch_kernel<2><<<total_blocks, 256, 0, st>>>((const long long*)descs_dev, ndesc, (const unsigned*)scratch,
+                                                           scratch + ndesc);
   CM_CHECK_LAUNCH();
   return 0;
+}
+
+long long cm_conv3x3_h3_packed_bytes(int k_channels, int out_channels) {
+  return cm_conv3x3_split_packed_bytes(k_channels, out_channels) / 3 * 2;
 }
 
 int cm_conv3x3_split(const float* in0, long long st0, int c0, const float* in1, long long st1, int c1,
@@ -510,29 +600,32 @@ int cm_conv3x3_split(const float* in0, long long st0, int c0, const float* in1, 
   config &= 0xff;
   if (a.ksplit > 1 && resid == out) return -22;   // the in-place residual would be zeroed
   a.tiles_x = a.tiles_y = 0;
-  a.xscale = a.oscale = 1.f;
+  a.winv = nullptr;
   return c1 > 0 ? dispatch_s<true, 3>(config, a, (hipStream_t)stream) : dispatch_s<false, 3>(config, a, (hipStream_t)stream);
 }
 
-/* EXPERIMENT (fp16x3): cm_conv3x3_split with two fp16 pieces / three products.  wps from cm_pack_conv3x3_h3_batch;
- * xscale: power of two applied to the input before the split; oscale = 1 / (xscale * wscale). */
+/* cm_conv3x3_split on two fp16 pieces per operand and three products ("fp16x3", csrc/split_f16.h): same contract and
+ * config encoding; wps / wscale_inv from cm_pack_conv3x3_h3_batch.  Input scaling is internal (running maximum). */
 int cm_conv3x3_h3(const float* in0, long long st0, int c0, const float* in1, long long st1, int c1, const void* wps,
-                  const float* bias, const float* resid, long long st_resid, float* out, long long st_out, int n, int h,
-                  int w, int cout, int config, float xscale, float oscale, cm_stream stream) {
-  if (n <= 0 || h <= 0 || w <= 0 || cout <= 0 || c0 <= 0 || c1 < 0 || config < 0) return -22;
+                  const float* wscale_inv, const float* bias, const float* resid, long long st_resid, float* out,
+                  long long st_out, int n, int h, int w, int cout, int config, cm_stream stream) {
+  if (n <= 0 || h <= 0 || w <= 0 || cout <= 0 || c0 <= 0 || c1 < 0 || config < 0 || !wscale_inv) return -22;
   if (c1 > 0 && (c0 % SKC) != 0) return -22;
   if (resid && st_resid != st_out) return -22;
-  if (bias || resid) return -22;             // (experiment: plain conv only)
   SplitArgs a;
   a.in0 = in0; a.in1 = in1; a.st0 = st0; a.st1 = st1; a.C0 = c0; a.C1 = c1;
   a.wps = (const u32x4*)wps; a.bias = bias; a.resid = resid; a.out = out; a.sto = st_out;
   a.N = n; a.H = h; a.W = w; a.Cout = cout;
   a.CoutP = ((cout + 31) / 32) * 32;
   a.nsteps = (c0 + c1 + SKC - 1) / SKC;
-  a.dbg = 0; a.prezeroed = 0; a.ksplit = 1;
+  a.dbg = 0;
+  a.prezeroed = (config >> 30) & 1;
+  config &= ~(1 << 30);
+  a.ksplit = config >> 8;
   config &= 0xff;
+  if (a.ksplit > 1 && resid == out) return -22;
   a.tiles_x = a.tiles_y = 0;
-  a.xscale = xscale; a.oscale = oscale;
+  a.winv = wscale_inv;
   return c1 > 0 ? dispatch_s<true, 2>(config, a, (hipStream_t)stream) : dispatch_s<false, 2>(config, a, (hipStream_t)stream);
 }
 

@@ -46,21 +46,30 @@ def _conv_jobs(p: Params, need_input_grad: bool):
     return jobs
 
 
-USE_SPLIT = os.environ.get("CM_CONV_BF16X6", "1") != "0"
+# Matrix-core numerics of the 3x3 convolutions (forward, data gradient, weight gradient), all fp32-equivalent:
+#   "fp16x3" (default): two fp16 pieces per operand, three products, exact power-of-two scaling (csrc/split_f16.h);
+#   "bf16x6": three bf16 pieces, six products (csrc/split_bf16.h);  "fp32": the exact fp32-MFMA kernels only.
+NUMERICS = os.environ.get("CM_CONV_NUMERICS", "fp16x3")
+if NUMERICS not in ("fp16x3", "bf16x6", "fp32"):
+    raise RuntimeError(f"CM_CONV_NUMERICS={NUMERICS!r}: expected fp16x3, bf16x6 or fp32")
+USE_SPLIT = NUMERICS == "bf16x6"
+USE_H3 = NUMERICS == "fp16x3"
 
 
 class _Packs:
     """Both operand forms of the packed 3x3 weights; ``conv(key, ...)`` lets the tuner choose the kernel family."""
 
-    def __init__(self, pk, pks, uses_fp32=None, packed_fp32=None, raw=None):
+    def __init__(self, pk, pks, uses_fp32=None, packed_fp32=None, raw=None, pkh=None, winv=None):
         self.pk, self.pks = pk, pks
+        self.pkh, self.winv = pkh or {}, winv or {}
         self.raw = raw or {}                      # key -> unpacked weight (few-input-channels forward kernel)
         self.uses_fp32 = uses_fp32 if uses_fp32 is not None else {}
         self.packed_fp32 = packed_fp32            # keys whose fp32-MFMA operand was re-packed this step (None = all)
 
     def conv(self, key, x0, cout, **kw):
         wp = self.pk[key] if (self.packed_fp32 is None or key in self.packed_fp32) else None
-        out = ops.conv3x3(x0, wp, cout, wps=self.pks.get(key), w_raw=self.raw.get(key), **kw)
+        out = ops.conv3x3(x0, wp, cout, wps=self.pks.get(key), w_raw=self.raw.get(key), wph=self.pkh.get(key),
+                          winv=self.winv.get(key), **kw)
         # (-1 = untuned fallback under graph capture, which runs the fp32-MFMA family)
         self.uses_fp32[key] = self.uses_fp32.get(key, False) or ops.LAST_CONV_CONFIG < ops.SPLIT_BASE
         return out
@@ -119,6 +128,27 @@ class Plan:
             rec.append([0, 0, 0, 0, 0, 0, 0, blk])
             self.spack_table = torch.tensor(rec, dtype=torch.int64).to(dev)
             self.spack_blocks = blk
+        # fp16x3 operand forms + their per-job inverse scales (scratch[njobs + j])
+        self.pkh: Dict[str, Tensor] = {}
+        self.winv: Dict[str, Tensor] = {}
+        if USE_H3:
+            hsz = []
+            for key, name, off, cin, dg in jobs:
+                w = p[name]
+                hsz.append(lib.cm_conv3x3_h3_packed_bytes(w.shape[0] if dg else cin, cin if dg else w.shape[0]) // 4)
+            self.wph_arena = torch.empty(sum(hsz), device=dev, dtype=torch.float32)
+            self.h3_scratch = torch.zeros(2 * len(jobs), device=dev, dtype=torch.float32)
+            rec, o, blk = [], 0, 0
+            for j, ((key, name, off, cin, dg), sz) in enumerate(zip(jobs, hsz)):
+                w = p[name]
+                self.pkh[key] = self.wph_arena[o:o + sz]
+                self.winv[key] = self.h3_scratch[len(jobs) + j:len(jobs) + j + 1]
+                rec.append([w.data_ptr(), self.pkh[key].data_ptr(), w.shape[0], w.shape[1], off, cin, dg, blk])
+                blk += max(1, min(512, (sz // 8 + 255) // 256))
+                o += sz
+            rec.append([0, 0, 0, 0, 0, 0, 0, blk])
+            self.hpack_table = torch.tensor(rec, dtype=torch.int64).to(dev)
+            self.hpack_blocks = blk
         self.gw: Dict[str, Tensor] = {}
         if g is not None:
             names = [n for n in p if n.endswith("body.0.weight") or n.endswith("body.3.weight")]
@@ -148,7 +178,7 @@ class Plan:
         st = torch.cuda.current_stream().cuda_stream
         table, n, blocks = self.pack_table, self.pack_n, self.pack_blocks
         packed = None
-        if self.pks and len(self.uses_fp32) == len(self._job_keys):
+        if (self.pks or self.pkh) and len(self.uses_fp32) == len(self._job_keys):
             # every conv has run at least once: pack the fp32-MFMA form only where that family is actually used
             need = frozenset(k for k in self._job_keys if self.uses_fp32[k])
             if self._pruned is None or self._pruned[0] != need:
@@ -169,7 +199,10 @@ class Plan:
         if self.pks:
             check(lib.cm_pack_conv3x3_split_batch(self.spack_table.data_ptr(), self.pack_n, self.spack_blocks, st),
                   "pack_split_batch")
-        return _Packs(self.pk, self.pks, self.uses_fp32, packed, self.raw)
+        if self.pkh:
+            check(lib.cm_pack_conv3x3_h3_batch(self.hpack_table.data_ptr(), self.pack_n, self.hpack_blocks,
+                                               self.h3_scratch.data_ptr(), st), "pack_h3_batch")
+        return _Packs(self.pk, self.pks, self.uses_fp32, packed, self.raw, self.pkh, self.winv)
 
     def zero_staging(self):
         _zero_(self.g_arena)

@@ -111,19 +111,22 @@ def pack_conv3x3(w, c_off=0, cin=None, dgrad=False):
 
 
 SPLIT_BASE = 1 << 20   # tuned configuration ids >= SPLIT_BASE select the bf16x6 kernel (cm_conv3x3_split)
+H3_BASE = 1 << 21      # ... ids >= H3_BASE the fp16x3 kernel (cm_conv3x3_h3 / cm_wgrad3x3_h3)
 SMALLC_CFG = 1 << 22   # tuned configuration id of the few-input-channels kernels (cm_conv3x3_smallc / cm_wgrad3x3_smallc)
 LAST_CONV_CONFIG = -1   # configuration the most recent conv3x3() call ran with (the engine prunes unused weight packs)
 
 
 def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1, wps=None, w_raw=None,
-            out_zeroed=False):
+            out_zeroed=False, wph=None, winv=None):
     """out = conv3x3(cat(x0, x1), wp) + bias + resid.  x0/x1: [N,C,H,W] (sample stride may exceed C*H*W).
 
     ``wp`` is the fp32-MFMA operand (cm_pack_conv3x3); ``wps`` (optional) the bf16x6 operand of the same weight;
     ``w_raw`` (optional) the unpacked [cout, cin, 3, 3] parameter, which adds the few-input-channels kernel
     (cm_conv3x3_smallc) to the candidates when cin * 9 <= 64.  ``out_zeroed``: the caller has filled ``out`` with
     zeros (one fill for several launches), so a K-split bf16x6 launch skips its own zero-fill launch.
-    With config < 0 the autotuner times both kernel families on this call signature and keeps the faster one."""
+    ``wph`` / ``winv`` (optional) the fp16x3 operand of the same weight and its inverse-scale scalar (pack_conv3x3_h3).
+    With config < 0 the autotuner times every kernel family it has an operand for on this call signature and keeps
+    the fastest."""
     n, c0, h, w = x0.shape
     c1 = 0 if x1 is None else x1.shape[1]
     if out is None:
@@ -139,6 +142,9 @@ def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1, w
             if cfg == SMALLC_CFG:
                 return lib.cm_conv3x3_smallc(_p(x0), x0.stride(0), c0, _p(w_raw), _p(bias), _p(_scratch[0]),
                                              _scratch[0].stride(0), n, h, w, cout, _stream())
+            if cfg >= H3_BASE:
+                return lib.cm_conv3x3_h3(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(wph), _p(winv), _p(bias), None, 0,
+                                         _p(_scratch[0]), _scratch[0].stride(0), n, h, w, cout, cfg - H3_BASE, _stream())
             if cfg >= SPLIT_BASE:
                 return lib.cm_conv3x3_split(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(wps), _p(bias), None, 0,
                                             _p(_scratch[0]), _scratch[0].stride(0), n, h, w, cout, cfg - SPLIT_BASE,
@@ -155,6 +161,11 @@ def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1, w
             ssplits = [1] + [k for k in (2, 4) if (c0 + c1) // 16 >= 4 * k and len(splits) > 1]
             cands += [SPLIT_BASE + c + ((k if k > 1 else 0) << 8) for c in range(lib.cm_conv3x3_split_num_configs())
                       for k in ssplits]
+        use_h3 = wph is not None and (c1 == 0 or c0 % 16 == 0)
+        if use_h3:
+            hsplits = [1] + [k for k in (2, 4) if (c0 + c1) // 16 >= 4 * k and len(splits) > 1]
+            cands += [H3_BASE + c + ((k if k > 1 else 0) << 8) for c in range(lib.cm_conv3x3_split_num_configs())
+                      for k in hsplits]
         use_smallc = (w_raw is not None and c1 == 0 and c0 * 9 <= 64 and w <= 320 and resid is None
                       and tuple(w_raw.shape) == (cout, c0, 3, 3) and w_raw.is_contiguous())
         if use_smallc:
@@ -163,15 +174,25 @@ def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1, w
             raise RuntimeError("conv3x3: no operand form usable for this call")
         # (same cache key with or without the fp32 operand: a caller that dropped it did so because the cached
         #  choice for its calls is a bf16x6 configuration)
-        key = ("conv3x3", n, h, w, c0, c1, cout, len(splits), use_split) + (("smallc",) if use_smallc else ())
-        config = _pick(key, cands, launch, -1 if wp is not None else SPLIT_BASE)
-        if wp is None and config < SPLIT_BASE:      # cached while the fp32 operand still existed: tune bf16x6 only
-            config = _pick(key + ("bf16x6",), cands, launch, SPLIT_BASE)
+        key = (("conv3x3", n, h, w, c0, c1, cout, len(splits), use_split) + (("smallc",) if use_smallc else ())
+               + (("h3",) if use_h3 else ()))
+        mfma16 = H3_BASE if use_h3 else SPLIT_BASE
+        config = _pick(key, cands, launch, -1 if wp is not None else mfma16)
+        if wp is None and config < SPLIT_BASE:      # cached while the fp32 operand still existed: tune the others only
+            config = _pick(key + ("no-fp32",), cands, launch, mfma16)
     global LAST_CONV_CONFIG
     LAST_CONV_CONFIG = config
     if config == SMALLC_CFG:
         check(lib.cm_conv3x3_smallc(_p(x0), x0.stride(0), c0, _p(w_raw), _p(bias), _p(out), out.stride(0), n, h, w, cout,
                                     _stream()), "conv3x3_smallc")
+        return out
+    if config >= H3_BASE:
+        cfg = config - H3_BASE
+        if out_zeroed and (cfg >> 8) > 1:
+            cfg |= 1 << 30
+        check(lib.cm_conv3x3_h3(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(wph), _p(winv), _p(bias), _p(resid),
+                                0 if resid is None else resid.stride(0), _p(out), out.stride(0), n, h, w, cout, cfg,
+                                _stream()), "conv3x3_h3")
         return out
     if config >= SPLIT_BASE:
         cfg = config - SPLIT_BASE
@@ -202,6 +223,21 @@ def pack_conv3x3_split(w, c_off=0, cin=None, dgrad=False):
 
 def _p_any(t):
     return t.data_ptr()
+
+
+def pack_conv3x3_h3(w, c_off=0, cin=None, dgrad=False):
+    """fp16x3 operand form of a 3x3 weight: returns (wph, winv) -- two fp16 pieces scaled by a power of two and the
+    device scalar that undoes the scale (single-job use of the batched packer; the engine batches all jobs)."""
+    cout, cin_total = w.shape[0], w.shape[1]
+    cin = cin_total - c_off if cin is None else cin
+    nbytes = lib.cm_conv3x3_h3_packed_bytes(cout if dgrad else cin, cin if dgrad else cout)
+    wph = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
+    scratch = torch.empty(2, device=w.device, dtype=torch.float32)
+    blocks = max(1, min(512, nbytes // 32 // 256 + 1))
+    table = torch.tensor([[w.data_ptr(), wph.data_ptr(), cout, cin_total, c_off, cin, int(dgrad), 0],
+                          [0, 0, 0, 0, 0, 0, 0, blocks]], dtype=torch.int64).to(w.device)
+    check(lib.cm_pack_conv3x3_h3_batch(_p_any(table), 1, blocks, _p(scratch), _stream()), "pack_h3")
+    return wph, scratch[1:]
 
 
 def conv3x3_split(x0, wps, cout, x1=None, bias=None, resid=None, out=None, config=0):

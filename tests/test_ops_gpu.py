@@ -595,3 +595,86 @@ def test_conv3x3_split_bf16x6(ops, case):
             y = ops.conv3x3_split(dev(x0), wps, cout, x1=None if x1 is None else dev(x1), bias=dev(b), resid=dev(r),
                                   config=cfg + (ks << 8))
             assert rel_l2(y, ref) < 2e-6, f"config {cfg} ksplit {ks}: {rel_l2(y, ref)}"
+
+
+# --------------------------------------------------------------------------------------------- fp16x3 numerics
+def _conv_h3(ops, x0, wph, winv, cout, x1=None, bias=None, resid=None, config=0):
+    from climate_amd._lib import lib, check
+    n, c0, h, w = x0.shape
+    out = torch.empty(n, cout, h, w, device="cuda")
+    check(lib.cm_conv3x3_h3(x0.data_ptr(), x0.stride(0), c0, None if x1 is None else x1.data_ptr(),
+                            0 if x1 is None else x1.stride(0), 0 if x1 is None else x1.shape[1], wph.data_ptr(),
+                            winv.data_ptr(), None if bias is None else bias.data_ptr(),
+                            None if resid is None else resid.data_ptr(), 0 if resid is None else resid.stride(0),
+                            out.data_ptr(), out.stride(0), n, h, w, cout, config,
+                            torch.cuda.current_stream().cuda_stream), "conv3x3_h3")
+    return out
+
+
+@pytest.mark.parametrize("case", [(3, 5, 0, 16, 16, 24), (2, 32, 32, 32, 12, 18), (5, 40, 0, 70, 10, 14),
+                                  (7, 64, 0, 64, 6, 9), (2, 32, 0, 8, 48, 72)])
+def test_conv3x3_fp16x3(ops, case):
+    """fp16x3 convolution (two fp16 pieces per operand, three MFMAs per k-step, exact power-of-two scaling): every tile
+    configuration, data-gradient form and K split at fp32-equivalent accuracy (2e-6 vs float64)."""
+    from climate_amd._lib import lib
+    n, c0, c1, cout, h, w = case
+    x0 = rnd(n, c0, h, w, seed=90)
+    x1 = rnd(n, c1, h, w, seed=91) if c1 else None
+    wt = rnd(cout, c0 + c1, 3, 3, seed=92, scale=(9 * (c0 + c1)) ** -0.5)
+    b = rnd(cout, seed=93); r = rnd(n, cout, h, w, seed=94)
+    xin = x0 if x1 is None else torch.cat([x0, x1], 1)
+    ref = F.conv2d(xin.double(), wt.double(), b.double(), padding=1) + r.double()
+    wph, winv = ops.pack_conv3x3_h3(dev(wt))
+    d1 = None if x1 is None else dev(x1)
+    for cfg in range(lib.cm_conv3x3_split_num_configs()):
+        y = _conv_h3(ops, dev(x0), wph, winv, cout, d1, dev(b), dev(r), cfg)
+        assert rel_l2(y, ref) < 2e-6, f"config {cfg}: {rel_l2(y, ref)}"
+    wpd, winvd = ops.pack_conv3x3_h3(dev(wt), dgrad=True)
+    dy = rnd(n, cout, h, w, seed=95)
+    xd = torch.zeros_like(xin, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xd, wt.double(), padding=1).backward(dy.double())
+    assert rel_l2(_conv_h3(ops, dev(dy), wpd, winvd, c0 + c1), xd.grad) < 2e-6
+    for cfg in (0, 5, 16):
+        for ks in (2, 3, 50):
+            y = _conv_h3(ops, dev(x0), wph, winv, cout, d1, dev(b), dev(r), cfg + (ks << 8))
+            assert rel_l2(y, ref) < 2e-6, f"config {cfg} ksplit {ks}: {rel_l2(y, ref)}"
+
+
+@pytest.mark.parametrize("xmag,wmag", [(1e-9, 1.0), (3e7, 1e-6), (1.0, 1e4), (1e-20, 1e-12), (1e15, 1e10)])
+def test_conv3x3_fp16x3_any_magnitude(ops, xmag, wmag):
+    """fp16 has five exponent bits; the kernel's power-of-two scaling must make the result independent of the operands'
+    magnitudes -- gradients of 1e-9, un-normalised inputs of 1e7, products beyond fp16's range."""
+    n, ci, co, h, w = 3, 48, 40, 12, 18
+    x = rnd(n, ci, h, w, seed=101) * xmag
+    wt = rnd(co, ci, 3, 3, seed=102, scale=(9 * ci) ** -0.5) * wmag
+    ref = F.conv2d(x.double(), wt.double(), padding=1)
+    wph, winv = ops.pack_conv3x3_h3(dev(wt))
+    for cfg in (0, 3, 5, 27):
+        y = _conv_h3(ops, dev(x), wph, winv, co, config=cfg)
+        assert torch.isfinite(y).all()
+        assert rel_l2(y, ref) < 2e-6, (cfg, rel_l2(y, ref))
+
+
+def test_conv3x3_fp16x3_mixed_ranges(ops):
+    """Magnitudes that differ by many orders INSIDE one tensor: channel groups at 1e-6 and 1e+4 (the running maximum
+    changes between the 16-channel stages, in both directions), whole samples at zero (left-padded frames), a sample
+    8 orders of magnitude above the rest.  Error is judged per sample against that sample's own scale."""
+    n, ci, co, h, w = 4, 64, 32, 12, 18
+    x = rnd(n, ci, h, w, seed=103)
+    x[:, 0:16] *= 1e-6
+    x[:, 16:32] *= 1e4
+    x[:, 32:48] *= 1e-2
+    x[1] = 0.0
+    x[2] *= 1e8
+    wt = rnd(co, ci, 3, 3, seed=104, scale=(9 * ci) ** -0.5)
+    ref = F.conv2d(x.double(), wt.double(), padding=1)
+    wph, winv = ops.pack_conv3x3_h3(dev(wt))
+    for cfg in (0, 3, 5, 7, 27):
+        y = _conv_h3(ops, dev(x), wph, winv, co, config=cfg)
+        assert torch.equal(y[1].cpu(), torch.zeros(co, h, w))
+        for s in (0, 2, 3):
+            assert rel_l2(y[s], ref[s]) < 2e-6, (cfg, s, rel_l2(y[s], ref[s]))
+    # inf / NaN propagate instead of disappearing
+    x[3, 5, 4, 4] = float("inf")
+    y = _conv_h3(ops, dev(x), wph, winv, co, config=0)
+    assert not torch.isfinite(y[3]).all()
