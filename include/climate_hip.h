@@ -68,7 +68,7 @@ int cm_conv3x3_split(const float* in0, long long st0, int c0, const float* in1, 
  * scaling: the weights per packed slice (cm_pack_conv3x3_h3_batch measures max |w|), the input per workgroup from the
  * running maximum of what it has staged (no history, no calibration, any magnitude; inf / NaN propagate).
  * cm_pack_conv3x3_h3_batch: descriptor records as cm_pack_conv3x3_batch with the wp field pointing at
- * cm_conv3x3_h3_packed_bytes() bytes; scratch = 2 * ndesc floats; scratch[ndesc + job] is that job's wscale_inv.     */
+ * cm_conv3x3_h3_packed_bytes() bytes; scratch = ndesc + total_blocks floats; scratch[job] is that job's wscale_inv.   */
 long long cm_conv3x3_h3_packed_bytes(int k_channels, int out_channels);
 int cm_pack_conv3x3_h3_batch(const void* descs_dev, int ndesc, int total_blocks, float* scratch, cm_stream stream);
 int cm_conv3x3_h3(const float* in0, long long st0, int c0, const float* in1, long long st1, int c1, const void* wps,

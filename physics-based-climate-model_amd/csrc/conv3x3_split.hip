@@ -142,7 +142,7 @@ __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void c
       wr[i] = wsrc[pc * piece_stride + (long long)th * a_CoutP + col];
     }
   };
-  auto store_chunk = [&](float xsc) {
+  auto store_chunk = [&](const float (&xsc_i)[NI]) {
     if (a.dbg & 8) return;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void c
         if constexpr (NP == 3)
           split3_pair(ok0 ? xr[i][2 * q] : 0.f, ok1 ? xr[i][2 * q + 1] : 0.f, a_, b_, c_);
         else
-          split2_pair_f16(ok0 ? xr[i][2 * q] * xsc : 0.f, ok1 ? xr[i][2 * q + 1] * xsc : 0.f, a_, b_);
+          split2_pair_f16(ok0 ? xr[i][2 * q] * xsc_i[i] : 0.f, ok1 ? xr[i][2 * q + 1] * xsc_i[i] : 0.f, a_, b_);
         ph[q] = a_; pm[q] = b_; pl[q] = c_;
       }
       if (e < ITEMS) {
@@ -203,58 +203,104 @@ __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void c
   const int cps = (nsteps + a.ksplit - 1) / a.ksplit;
   const int c_begin = blockIdx.z * cps, c_end = min(nsteps, c_begin + cps);
   if (c_begin >= c_end) return;
-  // fp16x3: the staged tile of every 16-channel stage is scaled by a power of two chosen from the RUNNING maximum of
-  // |x| over everything this workgroup has staged so far (exact: no history, no calibration, any input range).  Each
-  // wave posts the maximum of the registers it just loaded before the barrier that ends a stage; after it every thread
-  // combines the posts.  The scale can only shrink; when it does, the accumulators (which carry the scale) follow.
-  __shared__ float smax[2][WAVES];
-  unsigned be_cur = 0;                    // biased exponent of the running maximum (0 = nothing but zeros yet)
+  // fp16x3: every staged (sample, 16-channel stage) slab is scaled by a power of two chosen from the RUNNING maximum of
+  // |x| over everything this workgroup has staged of THAT SAMPLE so far (exact: no history, no calibration, any input
+  // range; samples of very different magnitude in one workgroup -- a left-padded frame next to a real one -- do not
+  // share a scale).  A GEMM column is a pixel of one sample and K runs over that sample's channels and taps, so a
+  // per-sample scale is constant along K; it lives per LANE on the accumulator side.  Each wave posts the per-sample
+  // maxima of the registers it just loaded (LDS atomic max) before the barrier that ends a stage; after it every thread
+  // combines the posts.  A scale can only shrink; when it does, the accumulators (which carry it) follow.
+  __shared__ unsigned smax[2][S];
+  unsigned be_run[S];                     // biased exponent of each sample's running maximum (0: only zeros so far)
+  unsigned be_col[NPT];                   // ... of the sample this lane's GEMM column p belongs to
+  int s_col[NPT], s_item[NI];
+#pragma unroll
+  for (int s_ = 0; s_ < S; ++s_) be_run[s_] = 0;
+#pragma unroll
+  for (int p = 0; p < NPT; ++p) {
+    const int q = min((wave * NPT + p) * 32 + l31, PIX - 1);
+    s_col[p] = q / (TH * TW);
+    be_col[p] = 0;
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) s_item[i] = ((tid + i * THREADS) % PH) / SS;
+  if constexpr (NP == 2) {
+    if (tid < 2 * S) smax[tid / S][tid % S] = 0u;
+    __syncthreads();
+  }
   auto post_max = [&](int buf) {
-    float m = 0.f;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int oct = (tid + i * THREADS) / PH;
+      float m = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const bool live = goff0[i] >= 0 && oct * 8 + j < cvalid_pending;     // exactly what store_chunk keeps
         m = fmaxf(m, live ? fabsf(xr[i][j]) : 0.f);
       }
+      if constexpr (S == 1) {
+        m = wave_max(m);
+        if (lane == 0) atomicMax(&smax[buf][0], __float_as_uint(m));
+      } else {
+        // one item's 64 lanes cover 64 consecutive haloed pixels: at most two samples (a sample has >= 88 of them)
+        const int first = __builtin_amdgcn_readfirstlane(s_item[i]);
+        const float ma = wave_max(s_item[i] == first ? m : 0.f), mb = wave_max(s_item[i] != first ? m : 0.f);
+        if (lane == 0) {
+          atomicMax(&smax[buf][first], __float_as_uint(ma));
+          if (first + 1 < S) atomicMax(&smax[buf][first + 1], __float_as_uint(mb));
+        }
+      }
     }
-    m = wave_max(m);
-    if (lane == 0) smax[buf][wave] = m;
   };
   // scale 2^(140 - be): the running maximum lands in [2^13, 2^14); its inverse 2^(be - 140)
   auto scale_of = [&](unsigned be) { return __uint_as_float((267u - max(be, 13u)) << 23); };
+  static_assert(S == 1 || (TH + 2) * (TW + 2) >= 64, "an item must not span more than two samples");
   load_chunk(c_begin);
   if constexpr (NP == 2) {
     post_max(0);
     __syncthreads();
   }
   for (int chunk = c_begin; chunk < c_end; ++chunk) {
-    float xsc = 1.f;
-    if constexpr (NP == 2) {
-      const int buf = (chunk - c_begin) & 1;
-      float m = 0.f;
+    float xsc_i[NI];
 #pragma unroll
-      for (int w_ = 0; w_ < WAVES; ++w_) m = fmaxf(m, smax[buf][w_]);
-      const unsigned be = max(be_cur, (__float_as_uint(m) >> 23) & 0xffu);     // (NaN / inf: be = 255, propagates)
-      if (be != be_cur) {
-        if (be_cur != 0) {                // accumulators hold sums at the old scale: bring them to the new one
-          const int d = (int)be - (int)be_cur;
-          const float f = d > 126 ? 0.f : __uint_as_float((unsigned)(127 - d) << 23);
+    for (int i = 0; i < NI; ++i) xsc_i[i] = 1.f;
+    const int pbuf = (chunk - c_begin) & 1;
+    if constexpr (NP == 2) {
+      bool changed = false;
+#pragma unroll
+      for (int s_ = 0; s_ < S; ++s_) {
+        const unsigned be = max(be_run[s_], (smax[pbuf][s_] >> 23) & 0xffu);  // (NaN / inf: be = 255, propagates)
+        changed |= be != be_run[s_];
+        be_run[s_] = be;
+      }
+      if (changed) {                      // (workgroup uniform) accumulators hold sums at the old scales: rescale them
+#pragma unroll
+        for (int p = 0; p < NPT; ++p) {
+          unsigned be = be_run[0];
+#pragma unroll
+          for (int s_ = 1; s_ < S; ++s_) be = s_col[p] == s_ ? be_run[s_] : be;
+          const int d = (int)be - (int)be_col[p];
+          const float f = (be_col[p] == 0 || d > 126) ? 0.f : __uint_as_float((unsigned)(127 - d) << 23);
+          be_col[p] = be;
 #pragma unroll
           for (int m_ = 0; m_ < WM; ++m_)
 #pragma unroll
-            for (int p = 0; p < NPT; ++p)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) acc[m_][p][r] *= f;
+            for (int r = 0; r < 16; ++r) acc[m_][p][r] *= f;       // (be_col was 0: nothing but zeros accumulated)
         }
-        be_cur = be;
       }
-      xsc = scale_of(be_cur);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        unsigned be = be_run[0];
+#pragma unroll
+        for (int s_ = 1; s_ < S; ++s_) be = s_item[i] == s_ ? be_run[s_] : be;
+        xsc_i[i] = scale_of(be);
+      }
     }
-    store_chunk(xsc);
+    store_chunk(xsc_i);
     __syncthreads();
+    if constexpr (NP == 2) {
+      if (tid < S) smax[pbuf][tid] = 0u;          // read by everyone before this barrier; re-posted two barriers on
+    }
     if (chunk + 1 < c_end) load_chunk(chunk + 1);
     if (!(a.dbg & 2))
 #pragma unroll
@@ -314,14 +360,15 @@ __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void c
   // ---- epilogue (same accumulator map as the fp32 kernel) ----
   if constexpr (NP == 2) {
     // undo the operand scales: 2^(be - 140) for the input (0 if nothing but zeros was staged), *winv for the weights
-    const float xinv = be_cur <= 13u ? 0.f : __uint_as_float((be_cur - 13u) << 23);
     const float winv = a.winv[0];
 #pragma unroll
-    for (int m = 0; m < WM; ++m)
+    for (int p = 0; p < NPT; ++p) {
+      const float xinv = be_col[p] <= 13u ? 0.f : __uint_as_float((be_col[p] - 13u) << 23);
 #pragma unroll
-      for (int p = 0; p < NPT; ++p)
+      for (int m = 0; m < WM; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][p][r] = (acc[m][p][r] * xinv) * winv;
+    }
   }
   if (a.bias && blockIdx.z == 0) {
 #pragma unroll
@@ -376,26 +423,36 @@ __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void c
 // ------------------------------------------------------------------------------------------------ packer
 // descs as cm_pack_conv3x3_batch: {w ptr, wps ptr, cout, cin_total, c_off, cin, dgrad, first block}
 // output record (piece, T = step*9 + tap, octet-half h, col) = 8 bf16 pieces of k-channels step*16 + h*8 + j
-// per-job max |w| over the slice the job packs (uint compare of non-negative float bits): scratch[d], zeroed before
-__global__ void weight_amax_batch_kernel(const long long* __restrict__ descs, int ndesc, unsigned* __restrict__ amax) {
+// Per-block maximum of |w| over the WHOLE weight tensor of the block's job (a superset of the slice the job packs: the
+// scale only has to be of the right order, and whole tensors stream as contiguous 16-byte loads): partial[blockIdx.x].
+__global__ void weight_amax_batch_kernel(const long long* __restrict__ descs, int ndesc, float* __restrict__ partial) {
+  __shared__ float red[4];
   int d = 0;
   while (d + 1 < ndesc && descs[(d + 1) * 8 + 7] <= (long long)blockIdx.x) ++d;
   const long long* r = descs + d * 8;
   const float* w = reinterpret_cast<const float*>(r[0]);
-  const int cout = (int)r[2], cin_total = (int)r[3], c_off = (int)r[4], cin = (int)r[5];
+  const long long total = r[2] * r[3] * 9;                 // cout * cin_total * 9 floats
   const int b0 = (int)r[7], nb = (int)descs[(d + 1) * 8 + 7] - b0;
-  const long long total = (long long)cout * cin * 9;
+  const long long t0 = (long long)(blockIdx.x - b0) * blockDim.x + threadIdx.x, stride = (long long)nb * blockDim.x;
   float m = 0.f;
-  for (long long i = (long long)(blockIdx.x - b0) * blockDim.x + threadIdx.x; i < total; i += (long long)nb * blockDim.x) {
-    const long long row = i / (cin * 9), rem = i % (cin * 9);
-    m = fmaxf(m, fabsf(w[(row * cin_total + c_off) * 9 + rem]));
+  if ((r[0] & 15) == 0) {
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(w);
+    for (long long i = t0; i < total / 4; i += stride) {
+      const f32x4 v = w4[i];
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    for (long long i = (total / 4) * 4 + t0; i < total; i += stride) m = fmaxf(m, fabsf(w[i]));
+  } else {
+    for (long long i = t0; i < total; i += stride) m = fmaxf(m, fabsf(w[i]));
   }
   m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) atomicMax(amax + d, __float_as_uint(m));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
 template <int NP>
-__global__ void pack_split_batch_kernel(const long long* __restrict__ descs, int ndesc, const unsigned* __restrict__ amax,
+__global__ void pack_split_batch_kernel(const long long* __restrict__ descs, int ndesc, const float* __restrict__ partial,
                                         float* __restrict__ winv_out) {
   int d = 0;
   while (d + 1 < ndesc && descs[(d + 1) * 8 + 7] <= (long long)blockIdx.x) ++d;
@@ -409,7 +466,14 @@ __global__ void pack_split_batch_kernel(const long long* __restrict__ descs, int
   const long long recs = (long long)nsteps * 9 * 2 * colsP;      // records per piece
   float wscale = 1.f;
   if constexpr (NP == 2) {              // largest weight -> [2^13, 2^14); the conv's epilogue multiplies by winv
-    const unsigned be = max((amax[d] >> 23) & 0xffu, 13u);
+    __shared__ float red[4];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) m = fmaxf(m, partial[b0 + i]);   // this job's block maxima
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const unsigned be = max((__float_as_uint(m) >> 23) & 0xffu, 13u);
     wscale = __uint_as_float((267u - be) << 23);
     if (blockIdx.x == b0 && threadIdx.x == 0) winv_out[d] = be <= 13u ? 0.f : __uint_as_float((be - 13u) << 23);
   }
@@ -563,15 +627,13 @@ int cm_pack_conv3x3_split_batch(const void* descs_dev, int ndesc, int total_bloc
 }
 
 /* fp16x3 operand form: same descriptor records as cm_pack_conv3x3_split_batch; every job's weight slice is scaled by
- * its own power of two (largest |w| -> [2^13, 2^14)) and split into two fp16 pieces.  scratch: 2*ndesc floats,
- * [0, ndesc) = workspace, [ndesc, 2*ndesc) = per-job inverse scales (pass &scratch[ndesc + job] to cm_conv3x3_h3). */
+ * a power of two (largest |w| of its tensor -> [2^13, 2^14)) and split into two fp16 pieces.  scratch: ndesc +
+ * total_blocks floats: [0, ndesc) = per-job inverse scales (pass &scratch[job] to cm_conv3x3_h3), the rest workspace. */
 int cm_pack_conv3x3_h3_batch(const void* descs_dev, int ndesc, int total_blocks, float* scratch, cm_stream stream) {
   if (ndesc <= 0 || total_blocks <= 0 || !scratch) return -22;
   hipStream_t st = (hipStream_t)stream;
-  zero_out_split_kernel<<<1, 256, 0, st>>>(scratch, 0, 1, ndesc);
-  weight_amax_batch_kernel<<<total_blocks, 256, 0, st>>>((const long long*)descs_dev, ndesc, (unsigned*)scratch);
-  pack_split_batch_kernel<2><<<total_blocks, 256, 0, st>>>((const long long*)descs_dev, ndesc, (const unsigned*)scratch,
-                                                           scratch + ndesc);
+  weight_amax_batch_kernel<<<total_blocks, 256, 0, st>>>((const long long*)descs_dev, ndesc, scratch + ndesc);
+  pack_split_batch_kernel<2><<<total_blocks, 256, 0, st>>>((const long long*)descs_dev, ndesc, scratch + ndesc, scratch);
   CM_CHECK_LAUNCH();
   return 0;
 }

@@ -137,18 +137,20 @@ class Plan:
                 w = p[name]
                 hsz.append(lib.cm_conv3x3_h3_packed_bytes(w.shape[0] if dg else cin, cin if dg else w.shape[0]) // 4)
             self.wph_arena = torch.empty(sum(hsz), device=dev, dtype=torch.float32)
-            self.h3_scratch = torch.zeros(2 * len(jobs), device=dev, dtype=torch.float32)
             rec, o, blk = [], 0, 0
             for j, ((key, name, off, cin, dg), sz) in enumerate(zip(jobs, hsz)):
                 w = p[name]
                 self.pkh[key] = self.wph_arena[o:o + sz]
-                self.winv[key] = self.h3_scratch[len(jobs) + j:len(jobs) + j + 1]
+                self._winv_slot = getattr(self, "_winv_slot", {})
+                self._winv_slot[key] = j
                 rec.append([w.data_ptr(), self.pkh[key].data_ptr(), w.shape[0], w.shape[1], off, cin, dg, blk])
                 blk += max(1, min(512, (sz // 8 + 255) // 256))
                 o += sz
             rec.append([0, 0, 0, 0, 0, 0, 0, blk])
             self.hpack_table = torch.tensor(rec, dtype=torch.int64).to(dev)
             self.hpack_blocks = blk
+            self.h3_scratch = torch.zeros(len(jobs) + blk, device=dev, dtype=torch.float32)
+            self.winv = {k: self.h3_scratch[j:j + 1] for k, j in self._winv_slot.items()}
         self.gw: Dict[str, Tensor] = {}
         if g is not None:
             names = [n for n in p if n.endswith("body.0.weight") or n.endswith("body.3.weight")]

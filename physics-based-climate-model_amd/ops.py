@@ -232,12 +232,12 @@ def pack_conv3x3_h3(w, c_off=0, cin=None, dgrad=False):
     cin = cin_total - c_off if cin is None else cin
     nbytes = lib.cm_conv3x3_h3_packed_bytes(cout if dgrad else cin, cin if dgrad else cout)
     wph = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
-    scratch = torch.empty(2, device=w.device, dtype=torch.float32)
     blocks = max(1, min(512, nbytes // 32 // 256 + 1))
+    scratch = torch.empty(1 + blocks, device=w.device, dtype=torch.float32)
     table = torch.tensor([[w.data_ptr(), wph.data_ptr(), cout, cin_total, c_off, cin, int(dgrad), 0],
                           [0, 0, 0, 0, 0, 0, 0, blocks]], dtype=torch.int64).to(w.device)
     check(lib.cm_pack_conv3x3_h3_batch(_p_any(table), 1, blocks, _p(scratch), _stream()), "pack_h3")
-    return wph, scratch[1:]
+    return wph, scratch[:1]
 
 
 def conv3x3_split(x0, wps, cout, x1=None, bias=None, resid=None, out=None, config=0):

@@ -14,22 +14,11 @@ from climate_amd._lib import check, lib  # noqa: E402
 from conv_microbench import layers, timeit  # noqa: E402
 
 
-def pack_h3(w, wscale):
-    cout, cin = w.shape[0], w.shape[1]
-    nbytes = lib.cm_conv3x3_split_packed_bytes(cin, cout) // 3 * 2
-    wps = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
-    blocks = max(1, min(512, nbytes // 32 // 256 + 1))
-    table = torch.tensor([[w.data_ptr(), wps.data_ptr(), cout, cin, 0, cin, 0, 0], [0, 0, 0, 0, 0, 0, 0, blocks]],
-                         dtype=torch.int64).to(w.device)
-    check(lib.cm_pack_conv3x3_h3_batch(table.data_ptr(), 1, blocks, wscale, torch.cuda.current_stream().cuda_stream), "pack_h3")
-    return wps
-
-
-def conv_h3(x0, wps, co, x1, out, cfg, xs, os_):
+def conv_h3(x0, wph, winv, co, x1, out, cfg):
     n, c0, h, w = x0.shape
     return lib.cm_conv3x3_h3(x0.data_ptr(), x0.stride(0), c0, None if x1 is None else x1.data_ptr(),
-                             0 if x1 is None else x1.stride(0), 0 if x1 is None else x1.shape[1], wps.data_ptr(), None,
-                             None, 0, out.data_ptr(), out.stride(0), n, h, w, co, cfg, xs, os_,
+                             0 if x1 is None else x1.stride(0), 0 if x1 is None else x1.shape[1], wph.data_ptr(),
+                             winv.data_ptr(), None, None, 0, out.data_ptr(), out.stride(0), n, h, w, co, cfg,
                              torch.cuda.current_stream().cuda_stream)
 
 
@@ -39,39 +28,38 @@ ap.add_argument("--base", type=int, default=32)
 args = ap.parse_args()
 only = set(filter(None, args.only.split(",")))
 tot = [0.0, 0.0]
+cases = []
 for name, n, c0, c1, co, h, w in layers(args.base, 32, 6):
     if name == "enc1.c1" or (only and name not in only):
         continue
+    cases.append((name, n, c0, c1, co, h, w))
+    cases.append((name + "/d", n, co, 0, c0 + c1, h, w))            # its data gradient: cout -> cin
+for name, n, c0, c1, co, h, w in cases:
     ci = c0 + c1
     x0 = torch.randn(n, c0, h, w, device="cuda")
     x1 = torch.randn(n, c1, h, w, device="cuda") if c1 else None
     wt = torch.randn(co, ci, 3, 3, device="cuda") * 0.05
     out = torch.empty(n, co, h, w, device="cuda")
     flops = 2.0 * n * h * w * co * ci * 9
-    xs, ws = 2.0 ** 10, 2.0 ** 16            # max|x| ~ 5 -> 5e3; max|w| ~ 0.25 -> 1.6e4
     wps3 = ops.pack_conv3x3_split(wt)
-    wps2 = pack_h3(wt, ws)
+    wph, winv = ops.pack_conv3x3_h3(wt)
     xc = torch.cat([x0, x1], 1) if c1 else x0
     ref = F.conv2d(xc[:2].double().cpu(), wt.double().cpu(), padding=1)
     res3, res2 = [], []
     for cfg in range(lib.cm_conv3x3_split_num_configs()):
         try:
-            t = timeit(lambda: ops.conv3x3_split(x0, wps3, co, x1=x1, out=out, config=cfg))
-            res3.append((t, cfg))
+            res3.append((timeit(lambda: ops.conv3x3_split(x0, wps3, co, x1=x1, out=out, config=cfg)), cfg))
         except RuntimeError:
             pass
-        if conv_h3(x0, wps2, co, x1, out, cfg, xs, 1.0 / (xs * ws)) == 0:
-            t = timeit(lambda: conv_h3(x0, wps2, co, x1, out, cfg, xs, 1.0 / (xs * ws)))
-            res2.append((t, cfg))
+        if conv_h3(x0, wph, winv, co, x1, out, cfg) == 0:
+            res2.append((timeit(lambda: conv_h3(x0, wph, winv, co, x1, out, cfg)), cfg))
     res3.sort(); res2.sort()
     ops.conv3x3_split(x0, wps3, co, x1=x1, out=out, config=res3[0][1])
     e3 = ((out[:2].double().cpu() - ref).norm() / ref.norm()).item()
-    conv_h3(x0, wps2, co, x1, out, res2[0][1], xs, 1.0 / (xs * ws))
+    conv_h3(x0, wph, winv, co, x1, out, res2[0][1])
     e2 = ((out[:2].double().cpu() - ref).norm() / ref.norm()).item()
-    f32 = F.conv2d(xc[:2].cpu(), wt.cpu(), padding=1)
-    ef = ((f32.double() - ref).norm() / ref.norm()).item()
     tot[0] += res3[0][0]; tot[1] += res2[0][0]
-    print(f"{name:8s} N={n:3d} {ci:3d}->{co:3d} @{h}x{w}: bf16x6 cfg {res3[0][1]:2d} {res3[0][0]:7.1f} us {flops / res3[0][0] / 1e6:6.1f} TF "
-          f"err {e3:.1e} | fp16x3 cfg {res2[0][1]:2d} {res2[0][0]:7.1f} us {flops / res2[0][0] / 1e6:6.1f} TF err {e2:.1e} "
-          f"| torch-CPU fp32 err {ef:.1e}")
+    print(f"{name:10s} N={n:3d} {ci:3d}->{co:3d} @{h}x{w}: bf16x6 cfg {res3[0][1]:2d} {res3[0][0]:7.1f} us {flops / res3[0][0] / 1e6:6.1f} TF "
+          f"err {e3:.1e} | fp16x3 cfg {res2[0][1]:2d} {res2[0][0]:7.1f} us {flops / res2[0][0] / 1e6:6.1f} TF err {e2:.1e}"
+          f" | next: " + " ".join(f"{c}:{t:.0f}" for t, c in res2[1:4]))
 print(f"sum of best: bf16x6 {tot[0]:.1f} us, fp16x3 {tot[1]:.1f} us")
