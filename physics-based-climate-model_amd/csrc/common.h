@@ -22,6 +22,21 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Maximum of NON-NEGATIVE floats over the wave (integer compare of the bit patterns), returned wave-uniform.  Six DPP
+// v_max steps (row shifts 1/2/4/8 inside the 16-lane rows, then row_bcast:15 / row_bcast:31 across rows) instead of six
+// dependent ds_bpermute round trips (~400 cycles of LDS-crossbar latency) that __shfl_xor costs.  NaN bit patterns
+// compare above +inf, so a NaN input yields a NaN-or-inf-class exponent downstream (what the callers want).
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+  int x = __float_as_int(v);
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true));    // row_shr:1 (lanes shifted in: 0)
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true));    // row_shr:2
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true));    // row_shr:4
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true));    // row_shr:8  -> lane 15 of a row = row max
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, true));    // row_bcast:15 into rows 1 and 3
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, true));    // row_bcast:31 into rows 2 and 3
+  return __int_as_float(__builtin_amdgcn_readlane(x, 63));
+}
+
 // Block-wide sum for blocks of up to 1024 threads; result valid in every thread. `red` needs >= 17 floats of LDS.
 __device__ __forceinline__ float block_sum(float v, float* red) {
   v = wave_sum(v);

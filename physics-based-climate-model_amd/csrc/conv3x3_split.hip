@@ -229,6 +229,7 @@ __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void c
     __syncthreads();
   }
   auto post_max = [&](int buf) {
+    float mi[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int oct = (tid + i * THREADS) / PH;
@@ -238,13 +239,21 @@ __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void c
         const bool live = goff0[i] >= 0 && oct * 8 + j < cvalid_pending;     // exactly what store_chunk keeps
         m = fmaxf(m, live ? fabsf(xr[i][j]) : 0.f);
       }
-      if constexpr (S == 1) {
-        m = wave_max(m);
-        if (lane == 0) atomicMax(&smax[buf][0], __float_as_uint(m));
-      } else {
+      mi[i] = m;
+    }
+    if constexpr (S == 1) {
+      float m = mi[0];
+#pragma unroll
+      for (int i = 1; i < NI; ++i) m = fmaxf(m, mi[i]);
+      m = wave_max_nonneg(m);
+      if (lane == 0) atomicMax(&smax[buf][0], __float_as_uint(m));
+    } else {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
         // one item's 64 lanes cover 64 consecutive haloed pixels: at most two samples (a sample has >= 88 of them)
         const int first = __builtin_amdgcn_readfirstlane(s_item[i]);
-        const float ma = wave_max(s_item[i] == first ? m : 0.f), mb = wave_max(s_item[i] != first ? m : 0.f);
+        const float ma = wave_max_nonneg(s_item[i] == first ? mi[i] : 0.f);
+        const float mb = wave_max_nonneg(s_item[i] != first ? mi[i] : 0.f);
         if (lane == 0) {
           atomicMax(&smax[buf][first], __float_as_uint(ma));
           if (first + 1 < S) atomicMax(&smax[buf][first + 1], __float_as_uint(mb));
