@@ -100,6 +100,10 @@ int cm_wgrad3x3_split_num_configs(void);
 int cm_wgrad3x3_split(const float* x0, long long sx0, int c0, const float* x1, long long sx1, int c1, const float* dy,
                       long long sdy, float* g, int ctot, int c_off, int n, int h, int w, int cout, int config,
                       cm_stream stream);
+/* fp16x3 form of cm_wgrad3x3_split: same arguments and configurations, half the matrix work (cm_conv3x3_h3). */
+int cm_wgrad3x3_h3(const float* x0, long long sx0, int c0, const float* x1, long long sx1, int c1, const float* dy,
+                   long long sdy, float* g, int ctot, int c_off, int n, int h, int w, int cout, int config,
+                   cm_stream stream);
 /* Weight gradient for VERY FEW input channels (cin * 9 <= 64, the first layer: src/unet.py:36 at
  * src/unet_convlstm_attention.py:35): GEMM columns are the (input channel, tap) pairs, fp32 MFMA, same staging
  * format G[cout][9][ctot].  w % 4 == 0, w <= 320, st_dy % 4 == 0.  scratch: cm_wgrad3x3_smallc_scratch_elems()

@@ -18,6 +18,7 @@
 // before the MFMAs of the current one; the pipeline does not drain between units.
 #include "common.h"
 #include "split_bf16.h"
+#include "split_f16.h"
 #include "../../include/climate_hip.h"
 
 namespace {
@@ -38,15 +39,15 @@ struct WsArgs {
 
 constexpr int cdiv_c(int a, int b) { return (a + b - 1) / b; }
 
-template <int TW, int MO, int KS>
+template <int TW, int MO, int KS, int NP = 3>
 struct WsGeom {
   static constexpr int NPAIR = (TW + 1) / 2;
   static constexpr int XCOLS = 2 * NPAIR + 2;   // dY positions 0..2*NPAIR-1 (zero beyond TW); X column = position + dx + 1
   static constexpr int XP = XCOLS | 1;          // odd record pitch: 32 channels hit distinct bank groups
   static constexpr int DP = (2 * NPAIR) | 1;
   static constexpr int BCO = 32 * MO;
-  static constexpr int XSLOT = 3 * 32 * XP;     // records of one ring slot (3 pieces)
-  static constexpr int STAGE = 3 * XSLOT + 3 * BCO * DP;
+  static constexpr int XSLOT = NP * 32 * XP;    // records of one ring slot (NP pieces)
+  static constexpr int STAGE = 3 * XSLOT + NP * BCO * DP;
   static constexpr int RED = (KS > 1) ? MO * 3 * 3 * 16 * 64 / 4 : 0;   // one wave set of accumulators, in records
   static constexpr size_t LDS = (size_t)(STAGE > RED ? STAGE : RED) * 16;
 };
@@ -56,15 +57,20 @@ struct WsGeom {
 // __launch_bounds__ argument is hip-clang's MIN WAVES PER EU).
 constexpr bool ws_lean(int mo, int ks) { return mo == 1 && ks == 2; }
 
-template <int TW, int MO, int KS, bool DUAL>
+// NP = 3: bf16x6; NP = 2: fp16x3 (split_f16.h).  fp16x3 scaling: one power of two per staged X row and per staged dY row,
+// from the RUNNING maxima of everything this workgroup has staged of each operand (exact, no history; the reduction
+// mixes samples, so its error is relative to the largest contributions, which is what a sum needs).  Every ring slot
+// remembers the shift it was converted with; a wave's accumulators carry the shift sum of the rows they last
+// accumulated, and follow when it shrinks (the sequence a wave sees is monotone).
+template <int TW, int MO, int KS, bool DUAL, int NP>
 __global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 3 : 1) void wgrad3x3_split_kernel(WsArgs a) {
-  using G = WsGeom<TW, MO, KS>;
+  using G = WsGeom<TW, MO, KS, NP>;
   constexpr int THREADS = 192 * KS;
   constexpr int NPAIR = G::NPAIR, XP = G::XP, DP = G::DP, BCO = G::BCO, XSLOT = G::XSLOT;
 
   extern __shared__ u32x4 lds[];
-  u32x4* const Xl = lds;                // [3 slots][3 pieces][32][XP]
-  u32x4* const Dl = lds + 3 * XSLOT;    // [3 pieces][BCO][DP]
+  u32x4* const Xl = lds;                // [3 slots][NP pieces][32][XP]
+  u32x4* const Dl = lds + 3 * XSLOT;    // [NP pieces][BCO][DP]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
@@ -96,7 +102,7 @@ __global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 3 : 1) void wgrad3x3_sp
   constexpr int NUNIT = 16 * NIT;                // conversion units (one split3_pair each) per thread and iteration
   // converting in the MFMA shadow keeps 48 result registers per item alive across the barrier: only where they fit
   constexpr bool LEAN = ws_lean(MO, KS);
-  constexpr bool SHADOW = NIT == 1 && MO == 1 && THREADS <= 384 && !LEAN;
+  constexpr bool SHADOW = NP == 3 && NIT == 1 && MO == 1 && THREADS <= 384 && !LEAN;   // (fp16x3: the scale is only known after the barrier)
   bool it_x[NIT];
   int it_ch[NIT], it_c0[NIT], it_rec[NIT];       // channel inside the tile, first column, first LDS record
 #pragma unroll
@@ -154,6 +160,16 @@ __global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 3 : 1) void wgrad3x3_sp
 
   f32x4 lr[NIT][8];        // prefetched quads: [item][sample]
   u32x4 cv[NIT][3][4];     // converted records: [item][piece][element]
+  // fp16x3 scaling state (all wave uniform).  shift = 140 - max(biased exponent of the running maximum, 13).
+  __shared__ unsigned smaxw[2][2];          // [iteration parity][X, dY] posted maxima (float bits, LDS atomic max)
+  unsigned bex_run = 0, bey_run = 0;
+  int slot_sh[3] = {127, 127, 127};         // shift each X ring slot was converted with
+  int d_sh = 127, d_sh_mma = 127;           // ... the dY row being staged / the one the MFMA phase reads
+  int acc_sx = 127, acc_sy = 127;           // shifts the accumulators currently carry (acc = true * 2^(sx + sy))
+  bool acc_any = false;
+  float xsc = 1.f, ysc = 1.f;
+  if (NP == 2 && tid < 4) smaxw[tid >> 1][tid & 1] = 0u;
+  int iter = 0;
   __syncthreads();
 
   while (true) {
@@ -196,8 +212,13 @@ __global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 3 : 1) void wgrad3x3_sp
     auto convert_unit = [&](int c) {
       const int k = c / 16, e = (c / 4) % 4, q = c % 4;
       const bool ok0 = ((it_msk[k] >> e) & 1) && 2 * q < nval, ok1 = ((it_msk[k] >> e) & 1) && 2 * q + 1 < nval;
-      unsigned a_, b_, c_;
-      split3_pair(ok0 ? lr[k][2 * q][e] : 0.f, ok1 ? lr[k][2 * q + 1][e] : 0.f, a_, b_, c_);
+      unsigned a_, b_, c_ = 0;
+      if constexpr (NP == 3) {
+        split3_pair(ok0 ? lr[k][2 * q][e] : 0.f, ok1 ? lr[k][2 * q + 1][e] : 0.f, a_, b_, c_);
+      } else {
+        const float sc = it_x[k] ? xsc : ysc;
+        split2_pair_f16(ok0 ? lr[k][2 * q][e] * sc : 0.f, ok1 ? lr[k][2 * q + 1][e] * sc : 0.f, a_, b_);
+      }
       cv[k][0][e][q] = a_;
       cv[k][1][e][q] = b_;
       cv[k][2][e][q] = c_;
@@ -214,21 +235,49 @@ __global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 3 : 1) void wgrad3x3_sp
         constexpr int JN = cdiv_c(NPAIR, KS);
         constexpr int NSTEP = JN * 3, S0 = NSTEP / 2, UPS = cdiv_c(NUNIT, NSTEP - S0);   // units per late step
         const int jb = ks * JN;
+        if constexpr (NP == 2) {          // bring the accumulators to the shift sum of the rows about to be accumulated
+          const int sx = slot_sh[(yy + 1) % 3], sy = d_sh_mma;
+          if (acc_any && sx + sy != acc_sx + acc_sy) {
+            const int d = (acc_sx + acc_sy) - (sx + sy);                    // >= 0: shifts only shrink
+            const float f = d > 126 ? 0.f : __uint_as_float((unsigned)(127 - d) << 23);
+#pragma unroll
+            for (int m = 0; m < MO; ++m)
+#pragma unroll
+              for (int dd = 0; dd < 3; ++dd)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][dd][r] *= f;
+          }
+          acc_sx = sx; acc_sy = sy; acc_any = true;
+        }
         const u32x4* xb = Xl + ((yy + 1) % 3) * XSLOT + l31 * XP + half + 1;
         const u32x4* db = Dl + l31 * DP + half;
-        bf16x8 af[2][MO][3], bf[2][3];
+        u32x4 af[2][MO][NP], bf[2][NP];
         auto load_a = [&](int buf, int jj) {
           const int j = min(jb + jj, NPAIR - 1);
 #pragma unroll
           for (int m = 0; m < MO; ++m)
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc)
-              af[buf][m][pc] = __builtin_bit_cast(bf16x8, db[(pc * BCO + m * 32) * DP + 2 * j]);
+            for (int pc = 0; pc < NP; ++pc) af[buf][m][pc] = db[(pc * BCO + m * 32) * DP + 2 * j];
         };
         auto load_b = [&](int buf, int jj, int d) {
           const int j = min(jb + jj, NPAIR - 1);
 #pragma unroll
-          for (int pc = 0; pc < 3; ++pc) bf[buf][pc] = __builtin_bit_cast(bf16x8, xb[pc * 32 * XP + 2 * j + d - 1]);
+          for (int pc = 0; pc < NP; ++pc) bf[buf][pc] = xb[pc * 32 * XP + 2 * j + d - 1];
+        };
+        auto mma = [&](const u32x4 (&A)[NP], const u32x4 (&B)[NP], f32x16 c) {
+          if constexpr (NP == 3) {
+            const bf16x8 a3[3] = {__builtin_bit_cast(bf16x8, A[0]), __builtin_bit_cast(bf16x8, A[1]),
+                                  __builtin_bit_cast(bf16x8, A[2])};
+            const bf16x8 b3[3] = {__builtin_bit_cast(bf16x8, B[0]), __builtin_bit_cast(bf16x8, B[1]),
+                                  __builtin_bit_cast(bf16x8, B[2])};
+            return mfma_bf16x6(a3, b3, c);
+          } else {
+            const f16x8 a0 = __builtin_bit_cast(f16x8, A[0]), a1 = __builtin_bit_cast(f16x8, A[1]);
+            const f16x8 b0 = __builtin_bit_cast(f16x8, B[0]), b1 = __builtin_bit_cast(f16x8, B[1]);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, c, 0, 0, 0);
+            return __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, c, 0, 0, 0);
+          }
         };
         if (LEAN) {
 #pragma unroll
@@ -238,7 +287,7 @@ __global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 3 : 1) void wgrad3x3_sp
             load_b(0, jj, d);
             if (NPAIR % KS == 0 || jb + jj < NPAIR) {
 #pragma unroll
-              for (int m = 0; m < MO; ++m) acc[m][d] = mfma_bf16x6(af[0][m], bf[0], acc[m][d]);
+              for (int m = 0; m < MO; ++m) acc[m][d] = mma(af[0][m], bf[0], acc[m][d]);
             }
           }
         } else {
@@ -255,7 +304,7 @@ __global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 3 : 1) void wgrad3x3_sp
             __builtin_amdgcn_sched_barrier(0);   // keep the reads of step s+1 ahead of the MFMAs of step s
             if (KS == 1 || NPAIR % KS == 0 || jb + jj < NPAIR) {
   #pragma unroll
-              for (int m = 0; m < MO; ++m) acc[m][d] = mfma_bf16x6(af[jj & 1][m], bf[s & 1], acc[m][d]);
+              for (int m = 0; m < MO; ++m) acc[m][d] = mma(af[jj & 1][m], bf[s & 1], acc[m][d]);
             }
             if (SHADOW && s >= S0 && !(a.dbg & 8)) {
   #pragma unroll
@@ -273,8 +322,42 @@ __global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 3 : 1) void wgrad3x3_sp
       for (int c = 0; c < NUNIT; ++c) convert_unit(c);
     }
 
+    // ---- fp16x3: post this iteration's maxima (the loads must have landed), combine them after the barrier ----
+    const int par = iter & 1;
+    if constexpr (NP == 2) {
+      float mx = 0.f, my = 0.f;
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const int row = it_x[k] ? xrow : drow;
+        if (row < 0) continue;
+        float m = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool live = (it_msk[k] >> e) & 1;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) m = fmaxf(m, (live && j < nval) ? fabsf(lr[k][j][e]) : 0.f);
+        }
+        mx = fmaxf(mx, it_x[k] ? m : 0.f);
+        my = fmaxf(my, it_x[k] ? 0.f : m);
+      }
+      mx = wave_max_nonneg(mx);
+      my = wave_max_nonneg(my);
+      if (lane == 0) {
+        atomicMax(&smaxw[par][0], __float_as_uint(mx));
+        atomicMax(&smaxw[par][1], __float_as_uint(my));
+      }
+    }
     // ---- store the converted rows ----
     __syncthreads();
+    if constexpr (NP == 2) {
+      bex_run = max(bex_run, (smaxw[par][0] >> 23) & 0xffu);
+      bey_run = max(bey_run, (smaxw[par][1] >> 23) & 0xffu);
+      const int shx = 140 - (int)max(bex_run, 13u), shy = 140 - (int)max(bey_run, 13u);
+      xsc = __uint_as_float((unsigned)(shx + 127) << 23);
+      ysc = __uint_as_float((unsigned)(shy + 127) << 23);
+      if (xrow >= 0) slot_sh[(xrow + 1) % 3] = shx;
+      d_sh = shy;
+    }
     if (!(a.dbg & 8)) {
 #pragma unroll
       for (int k = 0; k < NIT; ++k) {
@@ -291,12 +374,17 @@ __global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 3 : 1) void wgrad3x3_sp
         for (int e = 0; e < 4; ++e) {
           if (it_c0[k] + e < lim) {
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) dst[pc * pstride + it_rec[k] + e] = cv[k][pc][e];
+            for (int pc = 0; pc < NP; ++pc) dst[pc * pstride + it_rec[k] + e] = cv[k][pc][e];
           }
         }
       }
     }
     __syncthreads();
+    if constexpr (NP == 2) {
+      if (tid < 2) smaxw[par][tid] = 0u;     // everyone has read it; it is posted to again two iterations from now
+      d_sh_mma = d_sh;
+      ++iter;
+    }
     crow = drow;
     // ---- advance (unit, t) ----
     ++t;
@@ -308,6 +396,16 @@ __global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 3 : 1) void wgrad3x3_sp
     }
   }
 
+  if constexpr (NP == 2) {                 // undo the operand shifts (two exact steps: their sum may exceed fp32's range)
+    const float fx = acc_any ? __uint_as_float((unsigned)(127 - acc_sx) << 23) : 0.f;
+    const float fy = acc_any ? __uint_as_float((unsigned)(127 - acc_sy) << 23) : 0.f;
+#pragma unroll
+    for (int m = 0; m < MO; ++m)
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][d][r] = (acc[m][d][r] * fx) * fy;
+  }
   // ---- combine the KS shares of every kernel row through LDS, then one atomic per output element ----
   if (KS > 1) {
     float* red = reinterpret_cast<float*>(lds);
@@ -367,13 +465,13 @@ constexpr WsCfg kWs[] = {
 };
 constexpr int kNumWs = sizeof(kWs) / sizeof(kWs[0]);
 
-template <int I, bool DUAL>
+template <int I, bool DUAL, int NP>
 int launch_ws(WsArgs a, int rounds4, hipStream_t st) {
   constexpr WsCfg c = kWs[I];
-  using G = WsGeom<c.tw, c.mo, c.ks>;
+  using G = WsGeom<c.tw, c.mo, c.ks, NP>;
   constexpr size_t LDSB = G::LDS;
   constexpr int NTHR = 192 * c.ks;
-  auto kern = wgrad3x3_split_kernel<c.tw, c.mo, c.ks, DUAL>;
+  auto kern = wgrad3x3_split_kernel<c.tw, c.mo, c.ks, DUAL, NP>;
   static int occ = 0;
   if (occ == 0) {
     int nb = 0;
@@ -404,11 +502,11 @@ int launch_ws(WsArgs a, int rounds4, hipStream_t st) {
   return 0;
 }
 
-template <bool DUAL, int I = 0>
+template <bool DUAL, int NP, int I = 0>
 int dispatch_ws(int cfg, const WsArgs& a, int rounds4, hipStream_t st) {
   if constexpr (I < kNumWs) {
-    if (cfg == I) return launch_ws<I, DUAL>(a, rounds4, st);
-    return dispatch_ws<DUAL, I + 1>(cfg, a, rounds4, st);
+    if (cfg == I) return launch_ws<I, DUAL, NP>(a, rounds4, st);
+    return dispatch_ws<DUAL, NP, I + 1>(cfg, a, rounds4, st);
   } else {
     return -22;
   }
@@ -435,8 +533,28 @@ int cm_wgrad3x3_split(const float* x0, long long sx0, int c0, const float* x1, l
   a.dbg = s_dbg;
   const int rounds4 = (config >> 8) > 0 ? (config >> 8) : 4;   // bits 8.. = grid size in quarter rounds of resident slots
   config &= 0xff;
-  return c1 > 0 ? dispatch_ws<true>(config, a, rounds4, (hipStream_t)stream)
-                : dispatch_ws<false>(config, a, rounds4, (hipStream_t)stream);
+  return c1 > 0 ? dispatch_ws<true, 3>(config, a, rounds4, (hipStream_t)stream)
+                : dispatch_ws<false, 3>(config, a, rounds4, (hipStream_t)stream);
+}
+
+/* fp16x3 form of cm_wgrad3x3_split (same arguments, configurations and staging format; see cm_conv3x3_h3 and
+ * csrc/split_f16.h): two fp16 pieces per operand, three products, in-kernel power-of-two scaling. */
+int cm_wgrad3x3_h3(const float* x0, long long sx0, int c0, const float* x1, long long sx1, int c1, const float* dy,
+                   long long sdy, float* g, int ctot, int c_off, int n, int h, int w, int cout, int config,
+                   cm_stream stream) {
+  if (n <= 0 || h <= 0 || w <= 0 || cout <= 0 || c0 <= 0 || c1 < 0 || c_off < 0 || c_off + c0 + c1 > ctot || config < 0)
+    return -22;
+  if (c1 > 0 && (c0 % 32) != 0) return -22;
+  WsArgs a;
+  a.x0 = x0; a.x1 = x1; a.sx0 = sx0; a.sx1 = sx1; a.C0 = c0; a.C1 = c1;
+  a.dy = dy; a.sdy = sdy; a.g = g; a.Ctot = ctot; a.c_off = c_off;
+  a.N = n; a.H = h; a.W = w; a.Cout = cout;
+  a.RB = a.ngroups = a.nsegs = a.nunits = 0;
+  a.dbg = 0;
+  const int rounds4 = (config >> 8) > 0 ? (config >> 8) : 4;
+  config &= 0xff;
+  return c1 > 0 ? dispatch_ws<true, 2>(config, a, rounds4, (hipStream_t)stream)
+                : dispatch_ws<false, 2>(config, a, rounds4, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -251,7 +251,10 @@ def conv3x3_split(x0, wps, cout, x1=None, bias=None, resid=None, out=None, confi
     return out
 
 
-WGRAD_BF16X6 = os.environ.get("CM_WGRAD_BF16X6", "1") != "0"
+# Matrix-core numerics of the weight gradient: follows CM_CONV_NUMERICS (see engine.py): fp16x3 (default) / bf16x6 / fp32
+_WG_NUM = os.environ.get("CM_CONV_NUMERICS", "fp16x3")
+WGRAD_BF16X6 = _WG_NUM == "bf16x6"
+WGRAD_H3 = _WG_NUM == "fp16x3"
 
 
 def _wgrad_call(x0, dy, g, c_off, x1, config):
@@ -265,8 +268,12 @@ def _wgrad_call(x0, dy, g, c_off, x1, config):
         ws = torch.empty(int(lib.cm_wgrad3x3_smallc_scratch_elems(n, h, w, cout)), device=x0.device, dtype=torch.float32)
         return lib.cm_wgrad3x3_smallc(_p(x0), x0.stride(0), c0, _p(dy), dy.stride(0), _p(g), ctot, c_off, n, h, w, cout,
                                       _p(ws), _stream())
-    fn = lib.cm_wgrad3x3_split if config >= SPLIT_BASE else lib.cm_wgrad3x3
-    cfg = config - SPLIT_BASE if config >= SPLIT_BASE else config
+    if config >= H3_BASE:
+        fn, cfg = lib.cm_wgrad3x3_h3, config - H3_BASE
+    elif config >= SPLIT_BASE:
+        fn, cfg = lib.cm_wgrad3x3_split, config - SPLIT_BASE
+    else:
+        fn, cfg = lib.cm_wgrad3x3, config
     return fn(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(dy), dy.stride(0), _p(g), ctot, c_off, n, h, w, cout, cfg,
               _stream())
 
@@ -285,14 +292,12 @@ def wgrad3x3(x0, dy, g, c_off=0, x1=None, config=-1):
                 _scratch[0] = torch.empty_like(g)
             return _wgrad_call(x0, dy, _scratch[0], c_off, x1, cfg)
         cands = [c + (u << 8) for c in range(lib.cm_wgrad3x3_num_configs()) for u in (2, 3, 4, 6, 8)]
-        if WGRAD_BF16X6 and (c1 == 0 or c0 % 32 == 0):
-            only = os.environ.get("CM_WGS_ONLY")        # diagnostic: restrict to one bf16x6 configuration
-            ids = [int(only)] if only else range(lib.cm_wgrad3x3_split_num_configs())
-            split = [SPLIT_BASE + c + (u << 8) for c in ids for u in (2, 4, 8)]
-            cands = split if only else cands + split
+        if (WGRAD_BF16X6 or WGRAD_H3) and (c1 == 0 or c0 % 32 == 0):
+            base = H3_BASE if WGRAD_H3 else SPLIT_BASE
+            cands = cands + [base + c + (u << 8) for c in range(lib.cm_wgrad3x3_split_num_configs()) for u in (2, 4, 8)]
         if c1 == 0 and c0 * 9 <= 64 and w % 4 == 0 and w <= 320 and dy.stride(0) % 4 == 0:
             cands.append(SMALLC_CFG)
-        config = _pick(("wgrad3x3", n, h, w, c0, c1, cout, WGRAD_BF16X6), cands, launch, -1)
+        config = _pick(("wgrad3x3", n, h, w, c0, c1, cout, _WG_NUM), cands, launch, -1)
     check(_wgrad_call(x0, dy, g, c_off, x1, config), "wgrad3x3")
     return g
 

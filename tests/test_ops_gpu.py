@@ -678,3 +678,60 @@ def test_conv3x3_fp16x3_mixed_ranges(ops):
     x[3, 5, 4, 4] = float("inf")
     y = _conv_h3(ops, dev(x), wph, winv, co, config=0)
     assert not torch.isfinite(y[3]).all()
+
+
+@pytest.mark.parametrize("case", WGS_CASES)
+def test_wgrad3x3_fp16x3_all_configs(ops, case):
+    """fp16x3 weight gradient (cm_wgrad3x3_h3): every tile configuration and grid size vs float64 autograd."""
+    from climate_amd._lib import lib
+    n, c0, c1, cout, h, w = case
+    if c1 and c0 % 32:
+        pytest.skip("virtual concat needs a 32-aligned first input")
+    x0 = rnd(n, c0, h, w, seed=11)
+    x1 = rnd(n, c1, h, w, seed=12) if c1 else None
+    dy = rnd(n, cout, h, w, seed=13)
+    xin = x0 if x1 is None else torch.cat([x0, x1], 1)
+    wt = torch.zeros(cout, c0 + c1, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xin.double(), wt, padding=1).backward(dy.double())
+    ctot = c0 + c1 + 4
+    for i in range(lib.cm_wgrad3x3_split_num_configs()):
+        for rounds4 in (0, 1, 8):
+            cfg = ops.H3_BASE + i + (rounds4 << 8)
+            g = torch.zeros(cout, 9, ctot, device="cuda")
+            ops.wgrad3x3(dev(x0), dev(dy), g, c_off=4, x1=None if x1 is None else dev(x1), config=cfg)
+            dw = ops.wgrad3x3_unpack(g)
+            err = rel_l2(dw[:, 4:], wt.grad)
+            assert err < 2e-6, f"config {i}/{rounds4}: {err}"
+            assert dw[:, :4].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("xmag,dmag", [(1e-9, 1.0), (3e7, 1e-6), (1.0, 1e-12), (1e-20, 1e-15), (1e12, 1e9)])
+def test_wgrad3x3_fp16x3_any_magnitude(ops, xmag, dmag):
+    """Operand magnitudes far outside fp16's range (loss gradients of 1e-12, un-normalised activations) and rows whose
+    magnitude changes by orders during the reduction (the running maxima move, the ring slots keep their own shifts)."""
+    n, ci, co, h, w = 12, 32, 40, 12, 18
+    x = rnd(n, ci, h, w, seed=111) * xmag
+    dy = rnd(n, co, h, w, seed=112) * dmag
+    x[:, :, :4] *= 1e-5                    # the first rows of every image are much smaller ...
+    dy[:, :, 8:] *= 1e4                    # ... and the last rows of the gradient much larger
+    x[3] = 0.0                             # a left-padded (all-zero) frame
+    dy[5] *= 1e3
+    wt = torch.zeros(co, ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wt, padding=1).backward(dy.double())
+    for i in (0, 2, 4, 8, 12):
+        g = torch.zeros(co, 9, ci, device="cuda")
+        ops.wgrad3x3(dev(x), dev(dy), g, config=ops.H3_BASE + i + (2 << 8))
+        dw = ops.wgrad3x3_unpack(g)
+        assert torch.isfinite(dw).all()
+        assert rel_l2(dw, wt.grad) < 2e-6, (i, rel_l2(dw, wt.grad))
+
+
+def test_wgrad3x3_fp16x3_strided_samples(ops):
+    b, t, c, cout, h, w = 10, 3, 32, 32, 6, 9
+    xs = rnd(b, t, c, h, w, seed=21)
+    dys = rnd(b, t, cout, h, w, seed=22)
+    wt = torch.zeros(cout, c, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xs[:, 1].double(), wt, padding=1).backward(dys[:, 2].double())
+    g = torch.zeros(cout, 9, c, device="cuda")
+    ops.wgrad3x3(dev(xs)[:, 1], dev(dys)[:, 2], g, config=ops.H3_BASE + 0)
+    assert rel_l2(ops.wgrad3x3_unpack(g), wt.grad) < 2e-6
