@@ -250,13 +250,17 @@ __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void c
     } else {
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        // one item's 64 lanes cover 64 consecutive haloed pixels: at most two samples (a sample has >= 88 of them)
+        // one item's 64 lanes cover 64 consecutive records: at most two samples (a sample has >= 88 haloed pixels).
+        // The second one is NOT always first + 1: where the item straddles the boundary between the two channel octets
+        // the pixel index wraps from the last sample back to sample 0 -- so its id is read from a lane that has it.
         const int first = __builtin_amdgcn_readfirstlane(s_item[i]);
+        const unsigned long long othermask = __ballot(s_item[i] != first);
         const float ma = wave_max_nonneg(s_item[i] == first ? mi[i] : 0.f);
         const float mb = wave_max_nonneg(s_item[i] != first ? mi[i] : 0.f);
+        const int other = othermask ? __builtin_amdgcn_readlane(s_item[i], (int)__builtin_ctzll(othermask)) : first;
         if (lane == 0) {
           atomicMax(&smax[buf][first], __float_as_uint(ma));
-          if (first + 1 < S) atomicMax(&smax[buf][first + 1], __float_as_uint(mb));
+          if (othermask) atomicMax(&smax[buf][other], __float_as_uint(mb));
         }
       }
     }

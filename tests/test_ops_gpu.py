@@ -735,3 +735,21 @@ def test_wgrad3x3_fp16x3_strided_samples(ops):
     g = torch.zeros(cout, 9, c, device="cuda")
     ops.wgrad3x3(dev(xs)[:, 1], dev(dys)[:, 2], g, config=ops.H3_BASE + 0)
     assert rel_l2(ops.wgrad3x3_unpack(g), wt.grad) < 2e-6
+
+
+def test_conv3x3_fp16x3_sample_groups(ops):
+    """Tile configurations that put several 6x9 images into one workgroup: every sample keeps its own scale, also where
+    a staging item straddles the boundary between the two channel octets (pixel index wraps from the last sample back to
+    sample 0) -- sample 0's second octet is 3000x larger than everything else here, so a lost maximum means fp16 inf."""
+    n, ci, co, h, w = 12, 32, 32, 6, 9
+    x = rnd(n, ci, h, w, seed=121)
+    x[0::6, 8:16] *= 3e3
+    x[5::6] *= 1e-6
+    wt = rnd(co, ci, 3, 3, seed=122, scale=(9 * ci) ** -0.5)
+    ref = F.conv2d(x.double(), wt.double(), padding=1)
+    wph, winv = ops.pack_conv3x3_h3(dev(wt))
+    for cfg in (5, 6, 7, 8, 16, 17, 20, 21, 22, 23, 24, 25, 26):
+        y = _conv_h3(ops, dev(x), wph, winv, co, config=cfg)
+        assert torch.isfinite(y).all(), cfg
+        for s in range(n):
+            assert rel_l2(y[s], ref[s]) < 2e-6, (cfg, s, rel_l2(y[s], ref[s]))
