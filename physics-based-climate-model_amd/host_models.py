@@ -1,4 +1,5 @@
-"""Stock-torch members of the reference's model factory that are NOT on the MI355X hot path.
+"""Stock-torch members of the reference's model factory that are NOT on the MI355X hot path (SimpleCNN, and -- until
+its attention kernels exist -- cnn_transformer).
 
 ``SimpleCNN`` is BASELINE.json configs[0] ("SimpleCNN ... CPU PyTorch reference -- plumbing, no GPU"): the starter
 ResNet-style CNN of reference src/models.py:44-123.  It stays a plain ``nn.Module`` built from stock layers (it runs
@@ -7,6 +8,7 @@ reference; attribute names and registration order follow the reference so that `
 default initialisation under ``torch.manual_seed`` are identical (tests/test_host_cpu.py pins them against fixtures
 generated from the reference).
 """
+import torch
 import torch.nn as nn
 
 
@@ -59,3 +61,33 @@ class SimpleCNN(nn.Module):
         for blk in self.res_blocks:
             x = blk(x)
         return self.final(self.dropout(x))
+
+
+class CNNTransformer(nn.Module):
+    """Reference src/cnn_transformer.py:4-54 (BASELINE.json configs[3]): two stride-2 convs (48x72 -> 12x18 = 216
+    tokens), learned positional embedding, ``depth`` post-norm transformer encoder layers (ReLU MLP, dropout), two
+    2x2 transposed convs and a 1x1 head.  STOCK TORCH for now: this model type is served so that the factory is
+    complete and checkpoints interoperate, but it is not (yet) on the hand-written HIP path -- see DESIGN.md section 7.
+    x [B, in_channels, 48, 72] -> [B, out_channels, 48, 72]."""
+
+    def __init__(self, in_channels=5, out_channels=2, embed_dim=128, depth=4, n_heads=4, mlp_dim=256, dropout=0.1):
+        super().__init__()
+        half, quarter = embed_dim // 2, embed_dim // 4
+        self.encoder = nn.Sequential(nn.Conv2d(in_channels, half, kernel_size=3, stride=2, padding=1), nn.ReLU(),
+                                     nn.Conv2d(half, embed_dim, kernel_size=3, stride=2, padding=1), nn.ReLU())
+        self.height, self.width = 12, 18
+        self.num_tokens = self.height * self.width
+        self.embed_dim = embed_dim
+        self.pos_embedding = nn.Parameter(torch.randn(1, self.num_tokens, embed_dim))
+        layer = nn.TransformerEncoderLayer(d_model=embed_dim, nhead=n_heads, dim_feedforward=mlp_dim, dropout=dropout,
+                                           batch_first=True)
+        self.transformer = nn.TransformerEncoder(layer, num_layers=depth)
+        self.decoder = nn.Sequential(nn.ConvTranspose2d(embed_dim, half, kernel_size=2, stride=2), nn.ReLU(),
+                                     nn.ConvTranspose2d(half, quarter, kernel_size=2, stride=2), nn.ReLU(),
+                                     nn.Conv2d(quarter, out_channels, kernel_size=1))
+
+    def forward(self, x):
+        b = x.size(0)
+        tok = self.encoder(x).flatten(2).transpose(1, 2) + self.pos_embedding        # [B, 216, E]
+        tok = self.transformer(tok)
+        return self.decoder(tok.transpose(1, 2).reshape(b, self.embed_dim, self.height, self.width))

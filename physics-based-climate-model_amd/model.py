@@ -11,8 +11,8 @@ both ways, and the same default initialisation under ``torch.manual_seed``): the
 tensors to the engine (HIP kernels) through one ``autograd.Function`` so that the harness's ``loss.backward()``
 works unchanged.  There is no CPU path for these classes: a CPU input raises ``RuntimeError``.
 
-``SimpleCNN`` (BASELINE.json configs[0], "CPU plumbing, no GPU") and -- until its HIP path lands -- nothing else are
-stock-torch modules from ``host_models.py``.
+``SimpleCNN`` (BASELINE.json configs[0], "CPU plumbing, no GPU") and, until its attention kernels exist,
+``cnn_transformer`` are stock-torch modules from ``host_models.py``.
 """
 from typing import Dict, List
 
@@ -263,7 +263,7 @@ def get_model(cfg):
 
       * ``unet_convlstm_attention`` -> AttUNetConvLSTM on the HIP engine (the hot path);
       * ``unet``                    -> UNet on the HIP engine (same kernels, single frame);
-      * ``cnn_transformer``         -> CNNTransformer (``cnn_transformer.py``: HIP attention path);
+      * ``cnn_transformer``         -> CNNTransformer, stock torch for now (host_models.py; no HIP attention path yet);
       * ``SimpleCNN``               -> the stock-torch SimpleCNN (BASELINE configs[0]: "CPU PyTorch, plumbing").
 
     Differences from the reference, both deliberate: for ``unet_convlstm_attention`` ``in_ch`` is
@@ -283,7 +283,7 @@ def get_model(cfg):
         kwargs = {k: v for k, v in _items(cfg.model) if k != "type"}      # src/models.py:9-13
         return SimpleCNN(n_input_channels=n_in, n_output_channels=n_out, **kwargs)
     if mtype == "cnn_transformer":
-        from .cnn_transformer import CNNTransformer
+        from .host_models import CNNTransformer
         return CNNTransformer(in_channels=n_in, out_channels=n_out, embed_dim=int(cfg.model.embed_dim),
                               depth=int(cfg.model.depth), n_heads=int(cfg.model.n_heads),
                               mlp_dim=int(cfg.model.mlp_dim), dropout=float(cfg.model.dropout))

@@ -317,6 +317,22 @@ def main():
     npz("simple_cnn_default_cfg.npz", n_params=np.array(sum(p_.numel() for p_ in net.parameters())),
         names=np.array(list(net.state_dict().keys())))
 
+    # ---------------------------------------------------------------- cnn_transformer (src/cnn_transformer.py:4-54)
+    torch.manual_seed(42)
+    net = ct.CNNTransformer(in_channels=5, out_channels=2, embed_dim=32, depth=2, n_heads=4, mlp_dim=48, dropout=0.1)
+    names, sums = [], []
+    for k, v in net.state_dict().items():
+        names.append(k); sums.append(v.double().sum().item())
+    x = det_tensor((2, 5, 48, 72), 90.0)
+    net.eval()                          # dropout off: deterministic forward
+    xg = x.clone().requires_grad_()
+    yv = net(xg); yv.square().mean().backward()
+    npz("cnn_transformer_tiny.npz", names=np.array(names), sums=np.array(sums), x=x, y_eval=yv, dx=xg.grad,
+        g_pos=net.pos_embedding.grad, g_inproj0=net.transformer.layers[0].self_attn.in_proj_weight.grad)
+    net = ct.CNNTransformer(in_channels=5, out_channels=2, embed_dim=256, depth=6, n_heads=8, mlp_dim=256, dropout=0.1)
+    npz("cnn_transformer_cfg4.npz", n_params=np.array(sum(p_.numel() for p_ in net.parameters())),
+        names=np.array(list(net.state_dict().keys())))
+
 
 if __name__ == "__main__":
     main()

@@ -134,6 +134,35 @@ def test_factory_serves_every_reference_model_type():
         u(torch.zeros(1, 5, 8, 8))
 
 
+def test_cnn_transformer_matches_reference():
+    """model.type = cnn_transformer (src/cnn_transformer.py:4-54; BASELINE configs[3]): same state_dict, default init
+    under a seed, eval forward and gradients as the reference (stock torch: not on the HIP path yet)."""
+    import climate_amd
+    from climate_amd.config import load_config
+    from climate_amd.host_models import CNNTransformer
+    from climate_amd.model import get_model
+    g = load_golden("cnn_transformer_tiny.npz")
+    torch.manual_seed(42)
+    m = CNNTransformer(in_channels=5, out_channels=2, embed_dim=32, depth=2, n_heads=4, mlp_dim=48, dropout=0.1)
+    sd = m.state_dict()
+    assert list(sd) == g["names"].tolist()
+    for k, sm in zip(g["names"].tolist(), g["sums"].tolist()):
+        assert abs(sd[k].double().sum().item() - sm) < 1e-9, k
+    m.eval()
+    x = g["x"].clone().requires_grad_()
+    y = m(x); y.square().mean().backward()
+    assert torch.allclose(y, g["y_eval"], rtol=0, atol=2e-6)
+    assert torch.allclose(x.grad, g["dx"], rtol=1e-4, atol=1e-8)
+    assert torch.allclose(m.pos_embedding.grad, g["g_pos"], rtol=1e-4, atol=1e-8)
+    assert torch.allclose(m.transformer.layers[0].self_attn.in_proj_weight.grad, g["g_inproj0"], rtol=1e-4, atol=1e-8)
+    big = get_model(load_config(os.path.join(climate_amd._PKG_DIR, "configs"),
+                                overrides=["model=cnn_transformer", "model.embed_dim=256", "model.depth=6",
+                                           "model.n_heads=8"]))
+    c4 = load_golden("cnn_transformer_cfg4.npz")
+    assert isinstance(big, CNNTransformer) and list(big.state_dict()) == c4["names"].tolist()
+    assert sum(p.numel() for p in big.parameters()) == int(c4["n_params"]) == 2895170          # BASELINE.md section 2
+
+
 def test_simple_cnn_matches_reference():
     """Stock-torch SimpleCNN restatement vs the reference's (src/models.py:44-123): default init under a seed, eval
     forward, train-mode forward/backward (BatchNorm batch statistics + the Dropout2d mask stream)."""
