@@ -5,3 +5,4 @@ package; only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
 ``cpu_baseline`` leg may use it (as the checker / the timed CPU baseline).
 """
 from .cpu_ref import *  # noqa: F401,F403
+from . import data_ref  # noqa: F401

@@ -30,6 +30,9 @@ _CTYPES = {
     "const int*": ctypes.c_void_p,
     "int*": ctypes.c_void_p,
     "const long long*": ctypes.c_void_p,
+    "double": ctypes.c_double,
+    "double*": ctypes.c_void_p,
+    "const double*": ctypes.c_void_p,
     "const float* const*": ctypes.c_void_p,
     "float* const*": ctypes.c_void_p,
     "cm_engine*": ctypes.c_void_p,
