@@ -99,48 +99,66 @@ __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void c
     goff0[i] = ok ? (int)(s * a.st0) + sp : -1;
     if (DUAL) goff1[i] = ok ? (int)(s * a.st1) + sp : -1;
   }
+  // Global loads go through raw buffer instructions: a 32-bit per-lane BYTE offset that never changes over the K loop
+  // (sample, pixel, channel octet) + a wave-uniform scalar offset per (stage, channel) -- no 64-bit address arithmetic
+  // and no select per load; masked records (halo outside the image, samples past N) carry an offset beyond the
+  // descriptor's range, for which the hardware returns 0 without touching memory.  (The compiler turned the previous
+  // `src[ok ? off : 0]` form into ~4 64-bit VALU instructions and a branch per 4-byte load: 6 VALU per MFMA.)
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned voff0[NI], voff1[DUAL ? NI : 1], wvoff[NWR];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int oct = (tid + i * THREADS) / PH;
+    voff0[i] = goff0[i] >= 0 ? (unsigned)(goff0[i] + oct * 8 * HW) * 4u : OOB;
+    if (DUAL) voff1[i] = goff1[i] >= 0 ? (unsigned)(goff1[i] + oct * 8 * HW) * 4u : OOB;
+  }
+  const __amdgpu_buffer_rsrc_t rs0 =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_in0 + (long long)n0 * a_st0), 0, (int)OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(DUAL ? a_in1 + (long long)n0 * a_st1 : a_in0), 0, (int)OOB, 0x00020000);
 
   float xr[NI][8];
   u32x4 wr[NWR];
   int cvalid_pending = 0;
   const long long piece_stride = (long long)nsteps * 9 * 2 * a_CoutP;   // records per piece in the packed weights
 
+  // weight slab of one step: record r = ((piece*9 + tap)*2 + half)*BCO + col; per-lane part of its byte offset
+#pragma unroll
+  for (int i = 0; i < NWR; ++i) {
+    const int r = min(tid + i * THREADS, WREC - 1);
+    const int col = r % BCO, t2 = r / BCO;              // t2 = (piece*9 + tap)*2 + half
+    const int pc = t2 / 18, th = t2 % 18;
+    wvoff[i] = (unsigned)(pc * piece_stride + (long long)th * a_CoutP + col) * 16u;
+  }
+  const __amdgpu_buffer_rsrc_t rsw =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(a_wps + co0), 0, (int)OOB, 0x00020000);
+
   auto load_chunk = [&](int chunk) {
     const int ch0 = chunk * SKC;
-    const float* src;
-    int cvalid;
-    bool second = false;
-    if (!DUAL || ch0 < a_C0) {
-      src = a_in0 + (long long)n0 * a_st0 + (long long)ch0 * HW;
-      cvalid = a_C0 - ch0;
-    } else {
-      src = a_in1 + (long long)n0 * a_st1 + (long long)(ch0 - a_C0) * HW;
-      cvalid = a_C0 + a_C1 - ch0;
-      second = true;
-    }
+    const bool second = DUAL && ch0 >= a_C0;
+    const int cbase = second ? ch0 - a_C0 : ch0;                 // first channel of the stage inside its tensor
+    const int cvalid = (second ? a_C0 + a_C1 : a_C0) - ch0;      // channels of this stage that exist (<= 16 matter)
     cvalid_pending = cvalid;
     if (a.dbg & 1) return;
+    const __amdgpu_buffer_rsrc_t rs = second ? rs1 : rs0;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int e = tid + i * THREADS;
-      const int oct = e / PH;
-      const int off = (DUAL && second) ? goff1[i] : goff0[i];
+      const unsigned vo = second ? voff1[DUAL ? i : 0] : voff0[i];
+      if (cvalid >= SKC) {                                       // (wave uniform) every channel of the stage exists
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int c = oct * 8 + j;
-        const bool ok = off >= 0 && c < cvalid;
-        xr[i][j] = src[ok ? off + c * HW : 0];          // clamped address; zero-select happens at store time
+        for (int j = 0; j < 8; ++j)
+          xr[i][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, (cbase + j) * HW * 4, 0));
+      } else {                                                   // last stage of a channel count that is no multiple of 16
+        const int oct = (tid + i * THREADS) / PH;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          xr[i][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, oct * 8 + j < cvalid ? vo : OOB,
+                                                                           (cbase + j) * HW * 4, 0));
       }
     }
-    // weight slab of this step: record r = ((piece*9 + tap)*2 + half)*BCO + col
-    const u32x4* wsrc = a_wps + (long long)chunk * 9 * 2 * a_CoutP + co0;
+    const int wso = chunk * 9 * 2 * a_CoutP * 16;
 #pragma unroll
-    for (int i = 0; i < NWR; ++i) {
-      const int r = min(tid + i * THREADS, WREC - 1);
-      const int col = r % BCO, t2 = r / BCO;            // t2 = (piece*9 + tap)*2 + half
-      const int pc = t2 / 18, th = t2 % 18;
-      wr[i] = wsrc[pc * piece_stride + (long long)th * a_CoutP + col];
-    }
+    for (int i = 0; i < NWR; ++i) wr[i] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wvoff[i], wso, 0);
   };
   auto store_chunk = [&](const float (&xsc_i)[NI]) {
     if (a.dbg & 8) return;
@@ -151,13 +169,11 @@ __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void c
       u32x4 ph, pm, pl;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const bool ok0 = goff0[i] >= 0 && (oct * 8 + 2 * q) < cvalid_pending;
-        const bool ok1 = goff0[i] >= 0 && (oct * 8 + 2 * q + 1) < cvalid_pending;
-        unsigned a_, b_, c_ = 0;
+        unsigned a_, b_, c_ = 0;           // (masked records / channels were loaded as zeros: buffer range check)
         if constexpr (NP == 3)
-          split3_pair(ok0 ? xr[i][2 * q] : 0.f, ok1 ? xr[i][2 * q + 1] : 0.f, a_, b_, c_);
+          split3_pair(xr[i][2 * q], xr[i][2 * q + 1], a_, b_, c_);
         else
-          split2_pair_f16(ok0 ? xr[i][2 * q] * xsc_i[i] : 0.f, ok1 ? xr[i][2 * q + 1] * xsc_i[i] : 0.f, a_, b_);
+          split2_pair_f16(xr[i][2 * q] * xsc_i[i], xr[i][2 * q + 1] * xsc_i[i], a_, b_);
         ph[q] = a_; pm[q] = b_; pl[q] = c_;
       }
       if (e < ITEMS) {
@@ -232,13 +248,9 @@ __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void c
     float mi[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int oct = (tid + i * THREADS) / PH;
-      float m = 0.f;
+      float m = 0.f;                         // (masked records / channels hold zeros)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const bool live = goff0[i] >= 0 && oct * 8 + j < cvalid_pending;     // exactly what store_chunk keeps
-        m = fmaxf(m, live ? fabsf(xr[i][j]) : 0.f);
-      }
+      for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(xr[i][j]));
       mi[i] = m;
     }
     if constexpr (S == 1) {
@@ -619,6 +631,15 @@ int dispatch_s(int cfg, const SplitArgs& a, hipStream_t st) {
   }
 }
 
+// the kernels address a workgroup's samples (at most 7) and the packed weights with 32-bit byte offsets
+static bool offsets_fit_32bit(const SplitArgs& a) {
+  const long long hw4 = (long long)a.H * a.W * 4;
+  const long long lim = 0x7fffffffLL;
+  if (7 * a.st0 * 4 + (a.C0 + 16) * hw4 >= lim) return false;
+  if (a.C1 > 0 && 7 * a.st1 * 4 + (a.C1 + 16) * hw4 >= lim) return false;
+  return 3LL * a.nsteps * 9 * 2 * a.CoutP * 16 < lim;
+}
+
 }  // namespace
 
 extern "C" {
@@ -676,6 +697,7 @@ int cm_conv3x3_split(const float* in0, long long st0, int c0, const float* in1, 
   if (a.ksplit > 1 && resid == out) return -22;   // the in-place residual would be zeroed
   a.tiles_x = a.tiles_y = 0;
   a.winv = nullptr;
+  if (!offsets_fit_32bit(a)) return -22;
   return c1 > 0 ? dispatch_s<true, 3>(config, a, (hipStream_t)stream) : dispatch_s<false, 3>(config, a, (hipStream_t)stream);
 }
 
@@ -701,6 +723,7 @@ int cm_conv3x3_h3(const float* in0, long long st0, int c0, const float* in1, lon
   if (a.ksplit > 1 && resid == out) return -22;
   a.tiles_x = a.tiles_y = 0;
   a.winv = wscale_inv;
+  if (!offsets_fit_32bit(a)) return -22;
   return c1 > 0 ? dispatch_s<true, 2>(config, a, (hipStream_t)stream) : dispatch_s<false, 2>(config, a, (hipStream_t)stream);
 }
 
