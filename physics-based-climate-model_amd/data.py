@@ -40,7 +40,7 @@ class DeviceWindowDataset:
     def batch_into(self, idx: torch.Tensor, x: torch.Tensor, y: torch.Tensor) -> None:
         """Gather the samples ``idx`` (int64, on the device) into x [B,T,C,H,W] / y [B,C_out,H,W]."""
         b = idx.numel()
-        if tuple(x.shape) != (b, self.seq_len) + tuple(self.input_tensors.shape[1:]) or \\
+        if tuple(x.shape) != (b, self.seq_len) + tuple(self.input_tensors.shape[1:]) or \
                 tuple(y.shape) != (b,) + tuple(self.output_tensors.shape[1:]):
             raise RuntimeError("batch buffers do not match (B, seq_len, C, H, W) / (B, C_out, H, W)")
         if not (x.is_contiguous() and y.is_contiguous() and idx.is_cuda and idx.dtype == torch.int64):

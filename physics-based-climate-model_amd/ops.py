@@ -163,7 +163,7 @@ def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1, w
                       for k in ssplits]
         use_h3 = wph is not None and (c1 == 0 or c0 % 16 == 0)
         if use_h3:
-            hsplits = [1] + [k for k in (2, 4) if (c0 + c1) // 16 >= 4 * k and len(splits) > 1]
+            hsplits = [1] + [k for k in (2, 4, 8, 16) if (c0 + c1) // 16 >= 2 * k and len(splits) > 1]
             cands += [H3_BASE + c + ((k if k > 1 else 0) << 8) for c in range(lib.cm_conv3x3_split_num_configs())
                       for k in hsplits]
         use_smallc = (w_raw is not None and c1 == 0 and c0 * 9 <= 64 and w <= 320 and resid is None
