@@ -70,6 +70,7 @@ class DeviceLoader:
     def __init__(self, dataset: DeviceWindowDataset, batch_size: int, shuffle: bool = False, drop_last: bool = False,
                  generator: Optional[torch.Generator] = None, trainer=None):
         self.dataset, self.batch_size, self.trainer = dataset, int(batch_size), trainer
+        self.generator = generator
         sampler = RandomSampler(dataset, generator=generator) if shuffle else SequentialSampler(dataset)
         self.batch_sampler = BatchSampler(sampler, self.batch_size, drop_last)
 
@@ -79,6 +80,10 @@ class DeviceLoader:
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
         ds = self.dataset
         dev = ds.input_tensors.device
+        # torch's DataLoader draws its per-epoch base seed from the loader's generator BEFORE the sampler is iterated
+        # (torch/utils/data/dataloader.py, _BaseDataLoaderIter.__init__): one draw here keeps the generator's stream,
+        # hence the permutation, identical to the reference's DataLoader under the same generator.
+        torch.empty((), dtype=torch.int64).random_(generator=self.generator)
         for ids in self.batch_sampler:
             idx = torch.tensor(ids, dtype=torch.int64).to(dev, non_blocking=True)
             if self.trainer is not None and len(ids) == self.batch_size:
