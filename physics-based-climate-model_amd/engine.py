@@ -169,6 +169,19 @@ class Plan:
             rec.append([0, 0, 0, 0, 0, 0, 0, blk])
             self.unpack_table = torch.tensor(rec, dtype=torch.int64).to(dev)
             self.unpack_n, self.unpack_blocks = len(names), blk
+            # the same jobs split into the two gradient buckets of the data-parallel exchange: "late" = encoder (its
+            # backward runs last), "early" = ConvLSTM + decoder (ready first)
+            self._unpack_part = {}
+            for part, sel in (("late", lambda n: n.startswith("enc")), ("early", lambda n: not n.startswith("enc"))):
+                prec, pblk = [], 0
+                for n_, r_ in zip(names, rec[:-1]):
+                    if sel(n_):
+                        nb = max(1, min(512, (p[n_].numel() // 9 + 255) // 256))
+                        prec.append(r_[:7] + [pblk])
+                        pblk += nb
+                if prec:
+                    prec.append([0, 0, 0, 0, 0, 0, 0, pblk])
+                    self._unpack_part[part] = (torch.tensor(prec, dtype=torch.int64).to(dev), len(prec) - 1, pblk)
 
     @staticmethod
     def signature(p: Params, g: Optional[Params], need_input_grad: bool):
@@ -209,10 +222,14 @@ class Plan:
     def zero_staging(self):
         _zero_(self.g_arena)
 
-    def unpack(self):
+    def unpack(self, part=None):
+        """Transpose the staged weight gradients into parameter layout: everything, or one exchange bucket."""
         from ._lib import check, lib
-        check(lib.cm_wgrad3x3_unpack_batch(self.unpack_table.data_ptr(), self.unpack_n, self.unpack_blocks, 1.0,
-                                           torch.cuda.current_stream().cuda_stream), "unpack_batch")
+        table, n, blocks = (self.unpack_table, self.unpack_n, self.unpack_blocks) if part is None \
+            else self._unpack_part.get(part, (None, 0, 0))
+        if n > 0:
+            check(lib.cm_wgrad3x3_unpack_batch(table.data_ptr(), n, blocks, 1.0,
+                                               torch.cuda.current_stream().cuda_stream), "unpack_batch")
 
 
 _PLANS: "Dict[tuple, Plan]" = {}      # insertion order == recency (re-inserted on every hit)
@@ -524,22 +541,22 @@ def forward(p: Params, pk, x_seq: Tensor, save: bool = True, head: bool = True):
     return pred, sv
 
 
-def backward(p: Params, pk, g: Params, sv: Saved, dpred: Optional[Tensor], need_dx: bool = False,
-             dd1: Optional[Tensor] = None):
-    """Accumulates every parameter gradient into ``g`` (same keys as ``p``; the caller zeroes them) and returns
-    d(x_seq) when ``need_dx``.  ``post_conv.*`` is untouched (never used by the forward, as in the reference).
-    Either ``dpred`` (gradient w.r.t. the prediction) or ``dd1`` (gradient w.r.t. the head's input, with the head's
-    own parameter gradients already accumulated by ops.head_mse_bwd) is given."""
+class _BwdState:
+    """What the encoder half of the backward needs from the decoder / ConvLSTM half."""
+    __slots__ = ("plan", "ss", "side", "ds4", "dcat", "split")
+
+
+def backward_decoder_lstm(p: Params, pk, g: Params, sv: Saved, dpred: Optional[Tensor], need_dx: bool = False,
+                          dd1: Optional[Tensor] = None, bucketed: bool = False) -> "_BwdState":
+    """First half of the backward: head, decoder, ConvLSTM (BPTT).  When ``bucketed`` the weight gradients of these
+    layers are final (transposed into parameter layout) when this returns, so the data-parallel exchange of that
+    bucket can start while ``backward_encoder`` runs."""
     plan = get_plan(p, g, need_dx)
     gw = plan.gw
     plan.zero_staging()
     dev = (dpred if dpred is not None else dd1).device
     ss = _SideStream(dev, OVERLAP_WGRAD)
-    T = sv.T
-    c1, c2, c3, c4 = sv.enc
     u3, u2, u1 = sv.ups
-
-    # ---- head + decoder --------------------------------------------------------------------------------
     if dd1 is None:
         dd1 = ops.head_bwd(dpred, sv.d1, p["head.weight"], g["head.weight"], g["head.bias"])
     dec = _Deferred(OVERLAP_LSTM and not OVERLAP_WGRAD)      # decoder weight gradients: issued beside the LSTM chain
@@ -547,15 +564,28 @@ def backward(p: Params, pk, g: Params, sv: Saved, dpred: Optional[Tensor], need_
     dd2, dcat1 = up_bwd(p, pk, g, gw, dss, "up1.", u1, dd1)
     dd3, dcat2 = up_bwd(p, pk, g, gw, dss, "up2.", u2, dd2)
     dbott, dcat3 = up_bwd(p, pk, g, gw, dss, "up3.", u3, dd3)
-    b1, b2, b3 = u1[0].x0.shape[1], u2[0].x0.shape[1], u3[0].x0.shape[1]
-
-    # ---- ConvLSTM, back through time -------------------------------------------------------------------
     side = _SideStream(dev, dec.enabled)
     ds4 = convlstm_bwd(p, pk, g, gw, ss, sv.lstm, dbott,
                        before_chain=lambda: side.run(dec.flush, *list(dec.keep)))   # (kept alive until the join)
+    st = _BwdState()
+    st.plan, st.ss, st.side, st.ds4, st.dcat, st.split = plan, ss, side, ds4, (dcat1, dcat2, dcat3), bucketed
+    if bucketed:
+        ss.join()
+        side.join()
+        plan.unpack("early")
+    return st
 
-    # ---- encoder ---------------------------------------------------------------------------------------
-    dp3 = _block_bwd(p, pk, g, gw, ss, "enc4.conv.", c4, ds4)
+
+def backward_encoder(p: Params, pk, g: Params, sv: Saved, st: "_BwdState", need_dx: bool = False):
+    """Second half: the four encoder blocks over all frames (+ the skips' gradients, the pooling backward)."""
+    plan, ss = st.plan, st.ss
+    gw = plan.gw
+    T = sv.T
+    c1, c2, c3, c4 = sv.enc
+    u3, u2, u1 = sv.ups
+    dcat1, dcat2, dcat3 = st.dcat
+    b1, b2, b3 = u1[0].x0.shape[1], u2[0].x0.shape[1], u3[0].x0.shape[1]
+    dp3 = _block_bwd(p, pk, g, gw, ss, "enc4.conv.", c4, st.ds4)
     ds3 = ops.maxpool2_bwd(c3.out, dp3, dcat3[:, b3:], t=T)
     dp2 = _block_bwd(p, pk, g, gw, ss, "enc3.conv.", c3, ds3)
     ds2 = ops.maxpool2_bwd(c2.out, dp2, dcat2[:, b2:], t=T)
@@ -563,9 +593,19 @@ def backward(p: Params, pk, g: Params, sv: Saved, dpred: Optional[Tensor], need_
     ds1 = ops.maxpool2_bwd(c1.out, dp1, dcat1[:, b1:], t=T)
     dx = _block_bwd(p, pk, g, gw, ss, "enc1.", c1, ds1, need_dx=need_dx)
     ss.join()
-    side.join()
-    plan.unpack()
+    st.side.join()
+    plan.unpack("late" if st.split else None)
     return dx.view(sv.x_shape) if dx is not None else None
+
+
+def backward(p: Params, pk, g: Params, sv: Saved, dpred: Optional[Tensor], need_dx: bool = False,
+             dd1: Optional[Tensor] = None):
+    """Accumulates every parameter gradient into ``g`` (same keys as ``p``; the caller zeroes them) and returns
+    d(x_seq) when ``need_dx``.  ``post_conv.*`` is untouched (never used by the forward, as in the reference).
+    Either ``dpred`` (gradient w.r.t. the prediction) or ``dd1`` (gradient w.r.t. the head's input, with the head's
+    own parameter gradients already accumulated by ops.head_mse_bwd) is given."""
+    st = backward_decoder_lstm(p, pk, g, sv, dpred, need_dx=need_dx, dd1=dd1)
+    return backward_encoder(p, pk, g, sv, st, need_dx=need_dx)
 
 
 # ------------------------------------------------------------------------------------------------- plain UNet

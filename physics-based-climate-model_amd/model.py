@@ -214,6 +214,19 @@ class AttUNetConvLSTM(_HipModule):
     def _engine_backward(self, p, pk, g, sv, dpred, need_dx=False, dd1=None):
         return engine.backward(p, pk, g, sv, dpred, need_dx=need_dx, dd1=dd1)
 
+    # two-bucket form for the data-parallel trainer: the flat gradient buffer is laid out in registration order, so the
+    # encoder's gradients are its PREFIX [0, bucket_boundary) and ConvLSTM + decoder + head its SUFFIX
+    @property
+    def bucket_boundary(self) -> int:
+        lay = self._build_layout()
+        return lay["convlstm.cell.conv.weight"][0]
+
+    def _engine_backward_early(self, p, pk, g, sv, dd1):
+        return engine.backward_decoder_lstm(p, pk, g, sv, None, need_dx=False, dd1=dd1, bucketed=True)
+
+    def _engine_backward_late(self, p, pk, g, sv, st):
+        return engine.backward_encoder(p, pk, g, sv, st, need_dx=False)
+
 
 class UNet(_HipModule):
     """Depth-4 attention UNet on one frame (reference src/unet.py:72-109): x [B, in_ch, H, W] -> [B, out_ch, H, W].

@@ -1,5 +1,11 @@
 """Fused training step for the hot path: zero grads -> forward -> MSE -> backward -> [RCCL all-reduce] -> Adam.
 
+Data parallel (one process per GPU): the flat gradient is exchanged in TWO buckets.  The backward runs decoder and
+ConvLSTM first, the encoder last, and the flat buffer is in registration order, so the suffix {ConvLSTM, decoder, head}
+(2.6 M of 3.66 M floats at base 32) is final halfway through the backward: its all-reduce is issued then and runs on
+RCCL's stream beside the encoder's backward; only the encoder bucket's exchange is exposed.  (Lightning's DDP, which
+this replaces -- main_final.py:768 -- overlaps 25 MB buckets with autograd the same way.)
+
 Equivalent to one iteration of Lightning's automatic optimisation around ``training_step``
 (main_final.py:556-561, 737-747) with ``optimizer.zero_grad(); loss.backward(); optimizer.step()``, but scheduled
 directly on the engine: flat parameter / gradient / moment buffers, one fused Adam launch, and (optionally) the whole
@@ -41,9 +47,18 @@ class HotPathTrainer:
         self.steps = 0
         self.keep_saved = False   # debugging / tests: keep the last forward's saved activations in ``self.saved``
         self.saved = None
+        self.bucket_exchange = True   # world > 1: two gradient buckets, the first exchanged beside the encoder backward
+        self._mid = None
 
     # ------------------------------------------------------------------ pieces
-    def _fwd_bwd(self, x, y):
+    def _fwd_bwd(self, x, y, phase=None):
+        """phase None: the whole {zero, pack, forward, loss, backward}; "early": up to and including the decoder /
+        ConvLSTM half of the backward (its gradient bucket final); "late": the encoder half (needs "early" first)."""
+        if phase == "late":
+            p, pk, g, sv, st = self._mid
+            self.model._engine_backward_late(p, pk, g, sv, st)
+            self._mid = None
+            return
         p = self.model._param_dict()
         g = self.model._views(self.grad)
         check(lib.cm_zero(self._gradbuf.data_ptr(), (self.nt + 1) * 4, torch.cuda.current_stream().cuda_stream),
@@ -58,9 +73,12 @@ class HotPathTrainer:
         _, sv = self.model._engine_forward(p, pk, x, save=True, head=False)
         # output head + MSE + the head's backward: one pass over the last decoder activation
         dd1 = ops.head_mse_bwd(sv.d1, p["head.weight"], p["head.bias"], y, self.loss, g["head.weight"], g["head.bias"])
-        self.model._engine_backward(p, pk, g, sv, None, need_dx=False, dd1=dd1)
         if self.keep_saved:
             self.saved = sv
+        if phase == "early":
+            self._mid = (p, pk, g, sv, self.model._engine_backward_early(p, pk, g, sv, dd1))
+            return
+        self.model._engine_backward(p, pk, g, sv, None, need_dx=False, dd1=dd1)
 
     def _adam(self):
         b1, b2 = self.betas
@@ -68,10 +86,29 @@ class HotPathTrainer:
                                    self.nt, self.adam_state.data_ptr(), self.lr, b1, b2, self.eps, self.wd,
                                    1.0 / self.world, torch.cuda.current_stream().cuda_stream), "adam")
 
+    def _bucketed(self) -> bool:
+        return self.world > 1 and hasattr(self.model, "bucket_boundary") and self.bucket_exchange
+
+    def _exchange_early(self):
+        """SUM all-reduce of the {ConvLSTM, decoder, head} bucket, asynchronous: it runs on the backend's own stream
+        (which first waits for everything enqueued so far) while the caller enqueues the encoder's backward."""
+        return ddp.allreduce_gradients(self.grad[self.model.bucket_boundary:], async_op=True)[1]
+
+    def _exchange_late(self, early_work):
+        ddp.allreduce_gradients(self.grad[:self.model.bucket_boundary])
+        if early_work is not None:
+            early_work.wait()              # (stream-level wait: the Adam launch is ordered behind both exchanges)
+
     def _eager_step(self, x, y):
-        self._fwd_bwd(x, y)
-        if self.world > 1:
-            ddp.allreduce_gradients(self.grad)
+        if self._bucketed():
+            self._fwd_bwd(x, y, "early")
+            w = self._exchange_early()
+            self._fwd_bwd(x, y, "late")
+            self._exchange_late(w)
+        else:
+            self._fwd_bwd(x, y)
+            if self.world > 1:
+                ddp.allreduce_gradients(self.grad)
         self._adam()
 
     # ------------------------------------------------------------------ public
@@ -93,9 +130,14 @@ class HotPathTrainer:
             sx.copy_(x, non_blocking=True)
         if y.data_ptr() != sy.data_ptr():
             sy.copy_(y, non_blocking=True)
-        g1, g2 = self._graphs[key]
+        g1, g2, g3 = self._graphs[key]
         g1.replay()
-        if g2 is not None:                         # distributed: gradient exchange between the two graphs
+        if g3 is not None:                         # distributed, two buckets: exchange 1 runs beside graph 2
+            w = self._exchange_early()
+            g2.replay()
+            self._exchange_late(w)
+            g3.replay()
+        elif g2 is not None:                       # distributed, one bucket: gradient exchange between the two graphs
             ddp.allreduce_gradients(self.grad)
             g2.replay()
         return self.loss
@@ -166,16 +208,29 @@ class HotPathTrainer:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g1 = torch.cuda.CUDAGraph()
-        g2 = None
-        with torch.cuda.graph(g1):
-            self._fwd_bwd(sx, sy)
-            if self.world == 1:
-                self._adam()
-        if self.world > 1:
+        g2 = g3 = None
+        if self._bucketed():
+            # three graphs: {.., decoder + ConvLSTM backward} | exchange of bucket 1 beside {encoder backward} |
+            # exchange of bucket 2 | {Adam}.  The graphs share one memory pool: graph 2 reads activations graph 1 wrote.
+            pool = torch.cuda.graph_pool_handle()
+            with torch.cuda.graph(g1, pool=pool):
+                self._fwd_bwd(sx, sy, "early")
             g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2):
+            with torch.cuda.graph(g2, pool=pool):
+                self._fwd_bwd(sx, sy, "late")
+            g3 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g3, pool=pool):
                 self._adam()
-        self._graphs[key] = (g1, g2)
+        else:
+            with torch.cuda.graph(g1):
+                self._fwd_bwd(sx, sy)
+                if self.world == 1:
+                    self._adam()
+            if self.world > 1:
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2):
+                    self._adam()
+        self._graphs[key] = (g1, g2, g3)
 
 
 class InferenceRunner:

@@ -47,6 +47,13 @@ def _worker(rank, world, port, ret):
     p_ref = ref0[:nt].clone(); m2 = torch.zeros(nt); v2 = torch.zeros(nt)
     oracle.adam_reference_step(p_ref, gfull.mean(0), m2, v2, 1, lr=5e-4)
     assert torch.allclose(p, p_ref, atol=1e-7)
+    # two buckets, the first one asynchronous (what the trainer does beside the encoder's backward) == one exchange
+    g2 = gfull[rank].clone()
+    cut = 384
+    _, work = ddp.allreduce_gradients(g2[cut:], async_op=True)
+    ddp.allreduce_gradients(g2[:cut])
+    work.wait()
+    assert torch.allclose(g2, want, atol=1e-6)
     sl = ddp.shard_batch(64, rank, world)
     assert sl == slice(rank * 32, rank * 32 + 32)
     lg = ddp.mean_scalar(torch.tensor([float(rank)]))

@@ -279,3 +279,19 @@ def test_lightning_module_surface():
     assert len(g["params"]) == 75
     for name in ("forward", "training_step", "configure_optimizers"):
         assert callable(getattr(lm, name))
+
+
+def test_gradient_buckets_partition_the_flat_buffer():
+    """Two-bucket exchange (trainer.py): the encoder's gradients are exactly the prefix [0, bucket_boundary) of the
+    flat buffer, ConvLSTM + decoder + head exactly the rest of the trainable range; the staged weight-gradient unpack
+    jobs split the same way."""
+    from climate_amd.model import AttUNetConvLSTM
+    for base in (8, 32, 64):
+        m = AttUNetConvLSTM(5, 2, base, 6)
+        lay, b, nt = m._build_layout(), m.bucket_boundary, m.n_flat_trainable
+        assert 0 < b < nt and b % 64 == 0
+        for name in m._grad_names:
+            o, k, _ = lay[name]
+            assert (o + k <= b) == name.startswith("enc"), name
+            assert o + k <= nt
+        assert all(lay[n][0] >= nt for n in lay if n.startswith("post_conv."))
