@@ -34,13 +34,29 @@ PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak BW
 def load_pmc_traffic(launcher):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the
     gfx950 correction calibrated on this code's own 4-byte-per-lane kernels, + WRITE_SIZE); None if not collected."""
-    fam = {"cm_conv3x3_split": "conv3x3_split_kernel", "cm_conv3x3": "conv3x3_mfma_kernel"}[launcher]
+    fam = {"cm_conv3x3_h3": "conv3x3_split_kernel", "cm_conv3x3_split": "conv3x3_split_kernel",
+           "cm_conv3x3": "conv3x3_mfma_kernel"}[launcher]
     for path in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))[::-1]:
         try:
             d = json.load(open(path)).get(fam)
             if d:
                 return {"bytes_per_launch": round((2.0 * d["fetch_kib_per_launch"] + d["write_kib_per_launch"]) * 1024),
                         "source": os.path.relpath(path, ROOT)}
+        except Exception:
+            pass
+    return None
+
+
+def load_pmc_mfma(launcher):
+    """Matrix-core occupancy of the dominant kernel from the committed rocprofv3 --pmc pass (tools/measure_round.sh):
+    SQ_VALU_MFMA_BUSY_CYCLES summed over the chip / (1024 SIMDs x the kernel's duration in shader cycles)."""
+    fam = {"cm_conv3x3_h3": "conv3x3_split_kernel", "cm_conv3x3_split": "conv3x3_split_kernel",
+           "cm_conv3x3": "conv3x3_mfma_kernel"}[launcher]
+    for path in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*", "pmc_mfma.json")))[::-1]:
+        try:
+            d = json.load(open(path)).get(fam)
+            if d:
+                return dict(d, source=os.path.relpath(path, ROOT))
         except Exception:
             pass
     return None
@@ -254,11 +270,19 @@ def main():
             if d["bytes"] and not d["flops"]:
                 kernels[name]["gbps"] = round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1)
         # dominant kernel = the conv family that takes the most time in the step
-        cands = [(n, summ[n]) for n in ("cm_conv3x3_split", "cm_conv3x3") if n in summ]
+        cands = [(n, summ[n]) for n in ("cm_conv3x3_h3", "cm_conv3x3_split", "cm_conv3x3") if n in summ]
         if cands:
             name, c = max(cands, key=lambda kv: kv[1]["ms"])
             alg = c["flops"] / (c["ms"] * 1e-3) / 1e12
-            if name == "cm_conv3x3_split":
+            if name == "cm_conv3x3_h3":
+                # fp16x3: three f16 MFMAs are executed per algorithmic (fp32-equivalent) MAC group
+                roof = {"kernel": "conv3x3_split_kernel<.., NP=2> (cm_conv3x3_h3: forward + data-gradient launches, fp16x3)",
+                        "bound": "mfma", "achieved": round(3 * alg, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(3 * alg / PEAK_BF16_MFMA_TFLOPS, 4),
+                        "mfma_dtype": "f16 (2 pieces per fp32 operand, 3 products, fp32 accumulate; f16 = bf16 rate)",
+                        "algorithmic_tflops": round(alg, 2),
+                        "algorithmic_frac_of_3_product_ceiling": round(alg / (PEAK_BF16_MFMA_TFLOPS / 3), 4)}
+            elif name == "cm_conv3x3_split":
                 # bf16x6: six bf16 MFMAs are executed per algorithmic (fp32-equivalent) MAC group
                 roof = {"kernel": "conv3x3_split_kernel (cm_conv3x3_split: forward + data-gradient launches, bf16x6)",
                         "bound": "mfma", "achieved": round(6 * alg, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
@@ -269,7 +293,8 @@ def main():
                 roof = {"kernel": "conv3x3_mfma_kernel (cm_conv3x3: forward + data-gradient launches)",
                         "bound": "mfma", "achieved": round(alg, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(alg / PEAK_FP32_MFMA_TFLOPS, 4)}
-            roof.update({"traffic": load_pmc_traffic(name), "launches_per_step": c["calls"] / args.profile_steps,
+            roof.update({"traffic": load_pmc_traffic(name), "mfma_busy": load_pmc_mfma(name),
+                         "launches_per_step": c["calls"] / args.profile_steps,
                          "avg_launch_us": round(c["ms"] * 1e3 / c["calls"], 2)})
 
     cpu = None

@@ -6,7 +6,7 @@
 #   3. rocprofv3 --kernel-trace --stats of the same bench command (kernel_stats CSV)
 #   4. two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counters only, no trace domains) -> pmc_traffic.json
 set -o pipefail
-tag=${1:-r01}
+tag=${1:-r02}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -22,4 +22,8 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 benc
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 0 --no-graph > $out/pmc_write.log 2>&1
 python tools/pmc_traffic.py $out/pmc_fetch $out/pmc_write $out/pmc_traffic.json | head -8
 rm -rf $out/pmc_fetch $out/pmc_write
+#   5. matrix-core occupancy (north_star's "MFMA-busy counters"): SQ + GRBM counters, counters only
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_mfma -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 0 --no-graph > $out/pmc_mfma.log 2>&1
+python tools/pmc_mfma.py $out/pmc_mfma $out/pmc_mfma.json | head -8
+rm -rf $out/pmc_mfma
 ls -la $out
