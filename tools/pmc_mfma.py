@@ -16,7 +16,7 @@ from collections import defaultdict
 
 
 def family(name):
-    name = re.sub(r"\\(anonymous namespace\\)::", "", name)
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
     m = re.match(r"(?:void )?([A-Za-z0-9_]+)", name)
     return m.group(1) if m else name
 
