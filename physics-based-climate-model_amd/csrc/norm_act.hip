@@ -343,7 +343,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_reg_kernel(const float
 }
 
 template <int MODE, int MAXQ>
-__global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_reg_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(GN_THREADS, (MAXQ > 7 && MODE == 0) ? 3 : 1) void gn_silu_bwd_reg_kernel(const float* __restrict__ x,
                                                                        const float* __restrict__ gamma,
                                                                        const float* __restrict__ beta,
                                                                        const float* __restrict__ stats,
