@@ -252,6 +252,45 @@ int cm_eval_accumulate(const float* pred, const float* target, const double* par
 int cm_eval_finalize(const double* moments, const double* lat_w_dev, double count, double* out_dev, int c, int h, int w,
                      cm_stream stream);
 
+/* ---- cnn_transformer (BASELINE.json configs[3]; reference src/cnn_transformer.py:4-54) ---------------------------- *
+ * Dense GEMM on the f16 matrix cores, fp32-equivalent ("fp16x3", in-kernel power-of-two scaling, see cm_conv3x3_h3):
+ *   C[m,n] = relu?(op(A)[m,k] op(B)[k,n] + bias[n]) + resid[m % res_rows][n], then zeroed where mask[m][n] <= 0.
+ * trans_a = 0: A stored [m][k] (lda); 1: stored [k][m].  trans_b = 0: B stored [n][k] (ldb) -- an nn.Linear weight
+ * [out][in], so C = A W^T (F.linear: nn.TransformerEncoderLayer's in_proj / out_proj / linear1 / linear2,
+ * src/cnn_transformer.py:26-33) --; 1: stored [k][n].  ksplit > 1: K split over workgroups, raw sums accumulated with
+ * atomics into a C the caller zeroed (weight gradients: C = dY^T X with trans_a = trans_b = 1).                   */
+int cm_gemm_h3(const float* a, long long lda, int trans_a, const float* b, long long ldb, int trans_b, float* c,
+               long long ldc, const float* bias, const float* resid, long long ldr, int res_rows, const float* mask,
+               long long ldm, int relu, int m, int n, int k, int ksplit, cm_stream stream);
+/* post-norm residual LayerNorm, eps as given (nn.LayerNorm default 1e-5): sum_out = x + resid (nullable resid; kept for
+ * the backward), y = LN(sum_out) * gamma + beta, stats[m][2] = {mean, rstd}.  e <= 1024.                          */
+int cm_layernorm_fwd(const float* x, const float* resid, const float* gamma, const float* beta, float* sum_out, float* y,
+                     float* stats, int m, int e, float eps, cm_stream stream);
+/* ds = gradient wrt sum_in (flows to both residual branches); dgamma / dbeta ACCUMULATED.                         */
+int cm_layernorm_bwd(const float* sum_in, const float* stats, const float* gamma, const float* dy, float* ds,
+                     float* dgamma, float* dbeta, int m, int e, cm_stream stream);
+/* Multi-head self-attention core of nn.MultiheadAttention (batch_first, no mask, dropout off): qkv [b*s, 3e] = packed
+ * in_proj output; p [b, h, s, s] = softmax(q k^T / sqrt(d)) (kept for the backward); o [b*s, e] = p v, heads
+ * concatenated.  head_dim e/h in {8, 16, 32}, s <= 256.                                                           */
+int cm_attention_fwd(const float* qkv, float* p, float* o, int b, int s, int e, int h, cm_stream stream);
+/* dqkv [b*s, 3e] (all three column blocks written) from d_o [b*s, e]; ds_scratch [b, h, s, s] workspace.          */
+int cm_attention_bwd(const float* qkv, const float* p, const float* d_o, float* ds_scratch, float* dqkv, int b, int s,
+                     int e, int h, cm_stream stream);
+/* nn.Conv2d(cin, cout, 3, stride=2, padding=1) as im2col + cm_gemm_h3 (src/cnn_transformer.py:9-13): col
+ * [b*(h/2)*(w/2)][ldc], column ci*9 + tap, zero beyond cin*9; x NCHW (tokens_in = 0) or token-major [b*h*w][cin].
+ * cm_col2im_s2: the data gradient, token-major out.                                                                */
+int cm_im2col_s2(const float* x, float* col, int b, int cin, int h, int w, int ldc, int tokens_in, cm_stream stream);
+int cm_col2im_s2(const float* dcol, float* dx_tokens, int b, int cin, int h, int w, int ldc, cm_stream stream);
+/* out[batch][cols][rows] = in[batch][rows][cols]: tokens [b][s][e] <-> NCHW [b][e][s] (src/cnn_transformer.py:47,52) */
+int cm_transpose_batched(const float* in, float* out, int batch, int rows, int cols, cm_stream stream);
+int cm_relu(float* x, long long n, cm_stream stream);                         /* in place */
+int cm_relu_mask(float* g, const float* y, long long n, cm_stream stream);    /* g = y > 0 ? g : 0 (y = ReLU output) */
+/* out[r % period][c] += x[r][c] summed over r: period 1 = column sums (bias gradients), period s = the gradient of the
+ * positional embedding broadcast over the batch (src/cnn_transformer.py:48).  rows % period == 0.                  */
+int cm_rowgroup_sum(const float* x, float* out, long long rows, int cols, int period, cm_stream stream);
+/* out[r][c] = x[r][c] + add[r % period][c]: tokens + positional embedding (src/cnn_transformer.py:48) */
+int cm_add_rowgroup(const float* x, const float* add, float* out, long long rows, int cols, int period, cm_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,7 +37,7 @@ __all__ = [
     "se_block", "spatial_gate", "conv_block", "down_pool_enc", "up_block",
     "convlstm_cell", "convlstm", "model_forward", "training_loss",
     "adam_reference_step", "param_shapes", "closed_form_params", "GN_GROUPS", "GN_EPS",
-    "Decisions", "unet_forward", "unet_param_shapes",
+    "Decisions", "unet_forward", "unet_param_shapes", "cnn_transformer_forward",
 ]
 
 GN_GROUPS = 8       # nn.GroupNorm(8, c_out), src/unet.py:37,39
@@ -355,3 +355,33 @@ def closed_form_params(in_ch: int, out_ch: int, base: int, dtype=torch.float32, 
             val = 0.05 * wave
         out[name] = val.reshape(shape).to(dtype)
     return out
+
+
+# ----------------------------------------------------------------------------- cnn_transformer (BASELINE config 4)
+def cnn_transformer_forward(p: Params, x: Tensor, n_heads: int) -> Tensor:
+    """CNNTransformer.forward (src/cnn_transformer.py:44-54) with dropout OFF (eval mode / p = 0), spelled out with
+    functional ops: two stride-2 3x3 convs + ReLU -> 216 tokens + learned positional embedding -> ``depth`` post-norm
+    nn.TransformerEncoderLayer (batch_first, ReLU MLP, eps 1e-5) -> two 2x2 stride-2 transposed convs + ReLU -> 1x1.
+    Parameter names are the reference's state_dict keys."""
+    b = x.shape[0]
+    y = F.relu(F.conv2d(x, p["encoder.0.weight"], p["encoder.0.bias"], stride=2, padding=1))
+    y = F.relu(F.conv2d(y, p["encoder.2.weight"], p["encoder.2.bias"], stride=2, padding=1))
+    e, hh, ww = y.shape[1], y.shape[2], y.shape[3]
+    t = y.flatten(2).transpose(1, 2) + p["pos_embedding"]                      # [B, S, E]
+    depth = 1 + max(int(k.split(".")[2]) for k in p if k.startswith("transformer.layers."))
+    d = e // n_heads
+    for i in range(depth):
+        q = f"transformer.layers.{i}."
+        qkv = F.linear(t, p[q + "self_attn.in_proj_weight"], p[q + "self_attn.in_proj_bias"])
+        qh, kh, vh = (z.reshape(b, -1, n_heads, d).transpose(1, 2) for z in qkv.chunk(3, dim=-1))   # [B, H, S, d]
+        att = torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(d), dim=-1)
+        o = (att @ vh).transpose(1, 2).reshape(b, -1, e)
+        o = F.linear(o, p[q + "self_attn.out_proj.weight"], p[q + "self_attn.out_proj.bias"])
+        t = F.layer_norm(t + o, (e,), p[q + "norm1.weight"], p[q + "norm1.bias"], 1e-5)
+        m = F.linear(F.relu(F.linear(t, p[q + "linear1.weight"], p[q + "linear1.bias"])),
+                     p[q + "linear2.weight"], p[q + "linear2.bias"])
+        t = F.layer_norm(t + m, (e,), p[q + "norm2.weight"], p[q + "norm2.bias"], 1e-5)
+    y = t.transpose(1, 2).reshape(b, e, hh, ww)
+    y = F.relu(F.conv_transpose2d(y, p["decoder.0.weight"], p["decoder.0.bias"], stride=2))
+    y = F.relu(F.conv_transpose2d(y, p["decoder.2.weight"], p["decoder.2.bias"], stride=2))
+    return F.conv2d(y, p["decoder.4.weight"], p["decoder.4.bias"])

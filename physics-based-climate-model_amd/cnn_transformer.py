@@ -1,0 +1,190 @@
+"""``CNNTransformer`` on the MI355X HIP path (BASELINE.json configs[3]: embed 256, depth 6, 8 heads, 48x72, batch 64).
+
+Mirrors reference src/cnn_transformer.py:4-54 -- CNN encoder (two 3x3 stride-2 convs + ReLU: 48x72 -> 12x18 = 216
+tokens), learned positional embedding, ``depth`` post-norm ``nn.TransformerEncoderLayer`` (batch_first, ReLU MLP,
+LayerNorm eps 1e-5), CNN decoder (two 2x2 stride-2 transposed convs + ReLU, 1x1 conv) -- with the reference's exact
+``state_dict`` (the parameters live in the same stock containers, which are never called), driven by the same
+autograd bridge / fused trainer as the hot-path model.
+
+Schedule (every contraction on the f16 matrix cores with fp32-equivalent accuracy, ``cm_gemm_h3``):
+  conv 3x3 s2  = cm_im2col_s2 + GEMM (+ bias, ReLU)        token-major activations [B*S, C] from the first conv on
+  in_proj / out_proj / linear1 / linear2 = GEMM (F.linear), residual + LayerNorm = cm_layernorm_fwd
+  softmax(Q K^T / sqrt(d)) V = cm_attention_fwd             probabilities kept for the backward
+  decoder      = transpose to NCHW + the hot path's cm_convT2x2_* and 1x1 head kernels
+Backward: the same kernels' gradient forms (weight gradients are split-K GEMMs accumulating straight into the flat
+gradient buffer).
+
+DROPOUT: the reference trains this model with ``dropout=0.1`` (four sites per layer).  This path implements the
+dropout-free function -- ``model.eval()`` or ``dropout=0`` -- which is what the parity fixtures pin; calling it in
+training mode with ``dropout > 0`` raises instead of silently dropping the regulariser.
+"""
+import math
+from typing import Dict
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .model import _HipModule
+
+Tensor = torch.Tensor
+
+
+class _Saved:
+    pass
+
+
+def forward(p: Dict[str, Tensor], x: Tensor, n_heads: int, save: bool = True, head: bool = True):
+    """x [B, Cin, H, W] (H, W multiples of 4) -> pred [B, out, H, W], saved activations."""
+    if x.dim() != 4:
+        raise RuntimeError("expected x of shape [B, C, H, W]")
+    B, Cin, H, W = x.shape
+    if Cin != p["encoder.0.weight"].shape[1]:
+        raise RuntimeError(f"channel mismatch: input has {Cin} channels, the encoder expects "
+                           f"{p['encoder.0.weight'].shape[1]}")
+    S = (H // 4) * (W // 4)
+    if H % 4 or W % 4 or S != p["pos_embedding"].shape[1]:
+        raise RuntimeError(f"input grid {H}x{W} gives {S} tokens, the positional embedding has "
+                           f"{p['pos_embedding'].shape[1]} (reference: 48x72 -> 12x18 = 216)")
+    E2, E = p["encoder.0.weight"].shape[0], p["encoder.2.weight"].shape[0]
+    M1, M = B * (H // 2) * (W // 2), B * S
+    x = x.contiguous()
+    k1 = Cin * 9
+    col1 = ops.im2col_s2(x, B, Cin, H, W, (k1 + 3) // 4 * 4, tokens_in=False)
+    y1 = ops.gemm(col1, p["encoder.0.weight"].view(E2, k1), M1, E2, k1, bias=p["encoder.0.bias"], relu=True)
+    col2 = ops.im2col_s2(y1, B, E2, H // 2, W // 2, E2 * 9, tokens_in=True)
+    pos = p["pos_embedding"].view(S, E)
+    t0 = ops.gemm(col2, p["encoder.2.weight"].view(E, E2 * 9), M, E, E2 * 9, bias=p["encoder.2.bias"], relu=True)
+    t = _add_pos(t0, pos, S)            # the ReLU output t0 is kept: it is the mask of the conv's backward
+    depth = 1 + max(int(k.split(".")[2]) for k in p if k.startswith("transformer.layers."))
+    layers = []
+    for i in range(depth):
+        q = f"transformer.layers.{i}."
+        mlp = p[q + "linear1.weight"].shape[0]
+        qkv = ops.gemm(t, p[q + "self_attn.in_proj_weight"], M, 3 * E, E, bias=p[q + "self_attn.in_proj_bias"])
+        P, o = ops.attention_fwd(qkv, B, S, E, n_heads)
+        a = ops.gemm(o, p[q + "self_attn.out_proj.weight"], M, E, E, bias=p[q + "self_attn.out_proj.bias"])
+        t1, s1, st1 = ops.layernorm_fwd(a, t, p[q + "norm1.weight"], p[q + "norm1.bias"])
+        h1 = ops.gemm(t1, p[q + "linear1.weight"], M, mlp, E, bias=p[q + "linear1.bias"], relu=True)
+        m2 = ops.gemm(h1, p[q + "linear2.weight"], M, E, mlp, bias=p[q + "linear2.bias"])
+        t2, s2, st2 = ops.layernorm_fwd(m2, t1, p[q + "norm2.weight"], p[q + "norm2.bias"])
+        if save:
+            layers.append((t, qkv, P, o, s1, st1, t1, h1, s2, st2))
+        t = t2
+    z = ops.transpose_batched(t, B, S, E).view(B, E, H // 4, W // 4)
+    d1 = ops.relu_(ops.convT2x2_fwd(z, p["decoder.0.weight"], p["decoder.0.bias"]))
+    d2 = ops.relu_(ops.convT2x2_fwd(d1, p["decoder.2.weight"], p["decoder.2.bias"]))
+    pred = ops.head_fwd(d2, p["decoder.4.weight"], p["decoder.4.bias"]) if head else None
+    sv = None
+    if save:
+        sv = _Saved()
+        sv.shape, sv.col1, sv.y1, sv.col2, sv.t0, sv.layers, sv.z, sv.d1, sv.d2 = (B, Cin, H, W), col1, y1, col2, t0, layers, z, d1, d2
+        sv.d1_head = d2                   # input of the 1x1 head (the fused trainer's head+MSE launch reads it)
+    return pred, sv
+
+
+def _add_pos(t0: Tensor, pos: Tensor, S: int) -> Tensor:
+    """t0 [B*S, E] + pos [S, E] broadcast over the batch (x + self.pos_embedding, src/cnn_transformer.py:48)."""
+    from ._lib import check, lib
+    out = torch.empty_like(t0)
+    check(lib.cm_add_rowgroup(t0.data_ptr(), pos.data_ptr(), out.data_ptr(), t0.shape[0], t0.shape[1], S,
+                              torch.cuda.current_stream().cuda_stream), "add_rowgroup")
+    return out
+
+
+def _wgrad(dy: Tensor, x: Tensor, dw: Tensor, n_out: int, k_in: int, tokens: int):
+    """dw [n_out, k_in] += dy^T x  (dy [tokens, n_out], x [tokens, >= k_in]): split-K GEMM over the tokens."""
+    ks = max(1, min(64, tokens // 256))
+    ops.gemm(dy, x, n_out, k_in, tokens, trans_a=True, trans_b=True, out=dw.view(n_out, k_in), ksplit=ks)
+
+
+def backward(p: Dict[str, Tensor], g: Dict[str, Tensor], sv, n_heads: int, dpred=None, dd_head=None, need_dx=False):
+    """Accumulates every parameter gradient into ``g`` (zeroed by the caller).  Either ``dpred`` or ``dd_head`` (the
+    gradient wrt the 1x1 head's input, head gradients already accumulated) is given."""
+    B, Cin, H, W = sv.shape
+    S = (H // 4) * (W // 4)
+    E2, E = p["encoder.0.weight"].shape[0], p["encoder.2.weight"].shape[0]
+    M1, M = B * (H // 2) * (W // 2), B * S
+    if dd_head is None:
+        dd_head = ops.head_bwd(dpred, sv.d2, p["decoder.4.weight"], g["decoder.4.weight"], g["decoder.4.bias"])
+    dd2 = ops.relu_mask_(dd_head, sv.d2)
+    dd1 = ops.relu_mask_(ops.convT2x2_bwd(sv.d1, p["decoder.2.weight"], dd2, g["decoder.2.weight"], g["decoder.2.bias"]),
+                         sv.d1)
+    dz = ops.convT2x2_bwd(sv.z, p["decoder.0.weight"], dd1, g["decoder.0.weight"], g["decoder.0.bias"])
+    dt = ops.transpose_batched(dz.view(B, E, S), B, E, S).view(M, E)
+    for i in range(len(sv.layers) - 1, -1, -1):
+        q = f"transformer.layers.{i}."
+        t_in, qkv, P, o, s1, st1, t1, h1, s2, st2 = sv.layers[i]
+        mlp = h1.shape[1]
+        ds2 = ops.layernorm_bwd(s2, st2, p[q + "norm2.weight"], dt, g[q + "norm2.weight"], g[q + "norm2.bias"])
+        ops.rowgroup_sum(ds2, g[q + "linear2.bias"].view(1, E))
+        _wgrad(ds2, h1, g[q + "linear2.weight"], E, mlp, M)
+        dh1 = ops.gemm(ds2, p[q + "linear2.weight"], M, mlp, E, trans_b=True, mask=h1)        # through linear2 and the ReLU
+        ops.rowgroup_sum(dh1, g[q + "linear1.bias"].view(1, mlp))
+        _wgrad(dh1, t1, g[q + "linear1.weight"], mlp, E, M)
+        dt1 = ops.gemm(dh1, p[q + "linear1.weight"], M, E, mlp, trans_b=True, resid=ds2, res_rows=M)   # + residual branch
+        ds1 = ops.layernorm_bwd(s1, st1, p[q + "norm1.weight"], dt1, g[q + "norm1.weight"], g[q + "norm1.bias"])
+        ops.rowgroup_sum(ds1, g[q + "self_attn.out_proj.bias"].view(1, E))
+        _wgrad(ds1, o, g[q + "self_attn.out_proj.weight"], E, E, M)
+        d_o = ops.gemm(ds1, p[q + "self_attn.out_proj.weight"], M, E, E, trans_b=True)
+        dqkv = ops.attention_bwd(qkv, P, d_o, B, S, E, n_heads)
+        ops.rowgroup_sum(dqkv, g[q + "self_attn.in_proj_bias"].view(1, 3 * E))
+        _wgrad(dqkv, t_in, g[q + "self_attn.in_proj_weight"], 3 * E, E, M)
+        dt = ops.gemm(dqkv, p[q + "self_attn.in_proj_weight"], M, E, 3 * E, trans_b=True, resid=ds1, res_rows=M)
+    ops.rowgroup_sum(dt, g["pos_embedding"].view(S, E), period=S)
+    dt0 = ops.relu_mask_(dt, sv.t0)
+    ops.rowgroup_sum(dt0, g["encoder.2.bias"].view(1, E))
+    _wgrad(dt0, sv.col2, g["encoder.2.weight"], E, E2 * 9, M)
+    dcol2 = ops.gemm(dt0, p["encoder.2.weight"].view(E, E2 * 9), M, E2 * 9, E, trans_b=True)
+    dy1 = ops.relu_mask_(ops.col2im_s2(dcol2, B, E2, H // 2, W // 2), sv.y1)
+    ops.rowgroup_sum(dy1, g["encoder.0.bias"].view(1, E2))
+    _wgrad(dy1, sv.col1, g["encoder.0.weight"], E2, Cin * 9, M1)
+    if not need_dx:
+        return None
+    dcol1 = ops.gemm(dy1, p["encoder.0.weight"].view(E2, Cin * 9), M1, Cin * 9, E2, trans_b=True)
+    dx_tok = ops.col2im_s2(dcol1, B, Cin, H, W)                     # token-major [B*H*W, Cin]
+    return ops.transpose_batched(dx_tok.view(B, H * W, Cin), B, H * W, Cin).view(B, Cin, H, W)
+
+
+class CNNTransformer(_HipModule):
+    """Drop-in for the reference's ``CNNTransformer`` (same constructor, same state_dict) on the HIP path."""
+
+    _head_param_names = ("decoder.4.weight", "decoder.4.bias")
+
+    def __init__(self, in_channels=5, out_channels=2, embed_dim=128, depth=4, n_heads=4, mlp_dim=256, dropout=0.1):
+        super().__init__()
+        if embed_dim % n_heads or embed_dim // n_heads not in (8, 16, 32):
+            raise ValueError("head_dim = embed_dim / n_heads must be 8, 16 or 32 on the HIP attention kernel")
+        if embed_dim % 4 or embed_dim > 1024:
+            raise ValueError("embed_dim must be a multiple of 4 and <= 1024")
+        half, quarter = embed_dim // 2, embed_dim // 4
+        # registration order == reference __init__ (src/cnn_transformer.py:8-42); these containers are never called
+        self.encoder = nn.Sequential(nn.Conv2d(in_channels, half, kernel_size=3, stride=2, padding=1), nn.ReLU(),
+                                     nn.Conv2d(half, embed_dim, kernel_size=3, stride=2, padding=1), nn.ReLU())
+        self.height, self.width = 12, 18
+        self.num_tokens = self.height * self.width
+        self.embed_dim, self.n_heads, self.dropout_p = embed_dim, n_heads, float(dropout)
+        self.pos_embedding = nn.Parameter(torch.randn(1, self.num_tokens, embed_dim))
+        layer = nn.TransformerEncoderLayer(d_model=embed_dim, nhead=n_heads, dim_feedforward=mlp_dim, dropout=dropout,
+                                           batch_first=True)
+        self.transformer = nn.TransformerEncoder(layer, num_layers=depth)
+        self.decoder = nn.Sequential(nn.ConvTranspose2d(embed_dim, half, kernel_size=2, stride=2), nn.ReLU(),
+                                     nn.ConvTranspose2d(half, quarter, kernel_size=2, stride=2), nn.ReLU(),
+                                     nn.Conv2d(quarter, out_channels, kernel_size=1))
+        self._finish_init()
+
+    def _check_dropout(self):
+        if self.training and self.dropout_p > 0.0:
+            raise RuntimeError("CNNTransformer (climate_amd): the HIP path implements the dropout-free function; "
+                               f"training mode with dropout={self.dropout_p} is not available -- construct the model "
+                               "with model.dropout=0 or call .eval()")
+
+    def _engine_forward(self, p, pk, x, save=True, head=True):
+        self._check_dropout()
+        pred, sv = forward(p, x, self.n_heads, save=save, head=head)
+        if sv is not None:
+            sv.d1 = sv.d1_head
+        return pred, sv
+
+    def _engine_backward(self, p, pk, g, sv, dpred, need_dx=False, dd1=None):
+        return backward(p, g, sv, self.n_heads, dpred=dpred, dd_head=dd1, need_dx=need_dx)

@@ -1,0 +1,237 @@
+// Dense GEMM on the f16 matrix cores with fp32-equivalent accuracy ("fp16x3", see split_f16.h / conv3x3_split.hip):
+//   C[M,N] = mask(relu(op(A)[M,K] * op(B)[K,N] + bias[n]) + residual), fp32 in HBM on both sides.
+//
+// Used by the cnn_transformer path (BASELINE.json configs[3]; reference src/cnn_transformer.py): the linear layers of
+// nn.TransformerEncoderLayer (in_proj, out_proj, linear1, linear2 -- F.linear: y = x W^T + b), their data and weight
+// gradients, and the two stride-2 convolutions after im2col.
+//
+// Operand storage (row-major, leading dimension in elements):
+//   TA = false: A is [M][K]  (k contiguous)        TA = true: A is [K][M]  (m contiguous: a transposed view)
+//   TB = false: B is [N][K]  (k contiguous: W[out][in], so C = A W^T)      TB = true: B is [K][N] (n contiguous)
+// Every fp32 operand tile is split into two fp16 pieces on its way into LDS (records of 8 consecutive k of one row /
+// column = one 16-byte MFMA fragment) and multiplied as hi*hi + hi*lo + lo*hi with v_mfma_f32_32x32x16_f16.  Scaling:
+// one power of two per operand from the RUNNING maximum of what the workgroup has staged (exact, no calibration); the
+// accumulators follow when a scale shrinks.  Workgroup = 128 x 128 output tile, 4 waves as 2 x 2, 2 x 2 MFMA tiles per
+// wave, 32-deep K stages; blockIdx.z splits K (atomic accumulation into a zeroed C).
+#include "common.h"
+#include "split_f16.h"
+#include "../../include/climate_hip.h"
+
+namespace {
+
+typedef unsigned int gu32x4 __attribute__((ext_vector_type(4)));
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;      // [N] or null
+  const float* resid;     // [res_rows][ldr] or null: C += resid[m % res_rows][n]
+  const float* mask;      // [M][ldm] or null: C = mask[m][n] > 0 ? C : 0   (ReLU backward through a stored output)
+  long long lda, ldb, ldc, ldr, ldm;
+  int M, N, K, res_rows, relu, ksplit;
+};
+
+constexpr int GBM = 128, GBN = 128, GBK = 32;
+
+// stage one 128 x 32 operand tile: returns this thread's 16 values (two records of 8 consecutive k)
+//   k-contiguous storage: thread -> (row = tid / 2, k-half = tid % 2): four 16-byte loads along k
+//   row-contiguous storage (transposed view): thread -> (k octet = tid / 64, rows lane and lane + 64): 16 strided loads,
+//   each load instruction covering 64 consecutive rows of one k
+template <bool TRANS>
+__device__ __forceinline__ void gemm_load_tile(const float* __restrict__ P, long long ld, int rows, int K, int r0, int k0,
+                                               int tid, float (&v)[16]) {
+  if constexpr (!TRANS) {
+    const int row = r0 + (tid >> 1), kk = k0 + (tid & 1) * 16;
+    const bool rok = row < rows;
+    const float* src = P + (long long)(rok ? row : 0) * ld + kk;
+    const bool vec = (ld & 3) == 0 && (((uintptr_t)P) & 15) == 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (vec && rok && kk + 4 * q + 4 <= K) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(src + 4 * q);
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * q + e] = (rok && kk + 4 * q + e < K) ? src[4 * q + e] : 0.f;
+      }
+    }
+  } else {
+    const int ko = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = r0 + lane + 64 * h;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = k0 + ko * 8 + j;
+        v[8 * h + j] = (row < rows && k < K) ? P[(long long)k * ld + row] : 0.f;
+      }
+    }
+  }
+}
+
+// LDS record index of (row, k octet) inside a [piece][4 octets][128 rows] image
+template <bool TRANS>
+__device__ __forceinline__ void gemm_store_tile(gu32x4* __restrict__ L, int tid, const float (&v)[16], float sc) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    int row, oct;
+    if constexpr (!TRANS) { row = tid >> 1; oct = (tid & 1) * 2 + h; }
+    else                  { row = (tid & 63) + 64 * h; oct = tid >> 6; }
+    gu32x4 ph, pl;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned a_, b_;
+      split2_pair_f16(v[8 * h + 2 * q] * sc, v[8 * h + 2 * q + 1] * sc, a_, b_);
+      ph[q] = a_; pl[q] = b_;
+    }
+    L[(0 * 4 + oct) * 128 + row] = ph;
+    L[(1 * 4 + oct) * 128 + row] = pl;
+  }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
+  __shared__ gu32x4 Al[2 * 4 * 128], Bl[2 * 4 * 128];   // [piece][k octet][row / column]
+  __shared__ unsigned smax[2][2];                       // [stage parity][A, B] posted maxima
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+  const int nstage = (a.K + GBK - 1) / GBK;
+  const int sps = (nstage + a.ksplit - 1) / a.ksplit;
+  const int s_begin = blockIdx.z * sps, s_end = min(nstage, s_begin + sps);
+  if (s_begin >= s_end) return;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (tid < 4) smax[tid >> 1][tid & 1] = 0u;
+  __syncthreads();
+  float va[16], vb[16];
+  unsigned bea = 0, beb = 0;                 // biased exponents of the running maxima
+  auto post = [&](int par) {
+    float ma = 0.f, mb = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { ma = fmaxf(ma, fabsf(va[i])); mb = fmaxf(mb, fabsf(vb[i])); }
+    ma = wave_max_nonneg(ma);
+    mb = wave_max_nonneg(mb);
+    if (lane == 0) {
+      atomicMax(&smax[par][0], __float_as_uint(ma));
+      atomicMax(&smax[par][1], __float_as_uint(mb));
+    }
+  };
+  gemm_load_tile<TA>(a.A, a.lda, a.M, a.K, m0, s_begin * GBK, tid, va);
+  gemm_load_tile<TB>(a.B, a.ldb, a.N, a.K, n0, s_begin * GBK, tid, vb);
+  post(0);
+  __syncthreads();
+  for (int s = s_begin; s < s_end; ++s) {
+    const int par = (s - s_begin) & 1;
+    const unsigned na = max(bea, (smax[par][0] >> 23) & 0xffu), nb = max(beb, (smax[par][1] >> 23) & 0xffu);
+    if (na != bea || nb != beb) {            // (workgroup uniform) a scale shrank: the accumulators follow
+      if (bea != 0 || beb != 0) {
+        const int d = (int)(max(na, 13u) - max(bea, 13u)) + (int)(max(nb, 13u) - max(beb, 13u));
+        const float f = (bea == 0 || beb == 0 || d > 126) ? 0.f : __uint_as_float((unsigned)(127 - d) << 23);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] *= f;
+      }
+      bea = na; beb = nb;
+    }
+    const float sa = __uint_as_float((267u - max(bea, 13u)) << 23), sb = __uint_as_float((267u - max(beb, 13u)) << 23);
+    gemm_store_tile<TA>(Al, tid, va, sa);
+    gemm_store_tile<TB>(Bl, tid, vb, sb);
+    __syncthreads();
+    if (tid < 2) smax[par][tid] = 0u;
+    if (s + 1 < s_end) {
+      gemm_load_tile<TA>(a.A, a.lda, a.M, a.K, m0, (s + 1) * GBK, tid, va);
+      gemm_load_tile<TB>(a.B, a.ldb, a.N, a.K, n0, (s + 1) * GBK, tid, vb);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {         // two 16-deep MFMA k-steps per stage; the lane half picks the octet
+      const int oct = ks * 2 + half;
+      f16x8 af[2][2], bf[2][2];              // [piece][tile]
+#pragma unroll
+      for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          af[pc][t] = __builtin_bit_cast(f16x8, Al[(pc * 4 + oct) * 128 + wr * 64 + t * 32 + l31]);
+          bf[pc][t] = __builtin_bit_cast(f16x8, Bl[(pc * 4 + oct) * 128 + wc * 64 + t * 32 + l31]);
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (s + 1 < s_end) post(par ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: undo the scales, bias / residual / ReLU / mask, store (or accumulate for split K) ----
+  const float ia = bea <= 13u ? 0.f : __uint_as_float((bea - 13u) << 23);
+  const float ib = beb <= 13u ? 0.f : __uint_as_float((beb - 13u) << 23);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wc * 64 + j * 32 + l31;
+      if (n >= a.N) continue;
+      const float bv = (a.bias && blockIdx.z == 0) ? a.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m >= a.M) continue;
+        float v = (acc[i][j][r] * ia) * ib + bv;
+        if (a.ksplit > 1) {
+          unsafeAtomicAdd(a.C + (long long)m * a.ldc + n, v);
+          continue;
+        }
+        if (a.relu) v = fmaxf(v, 0.f);                              // (ReLU first: relu(conv) + pos_embedding)
+        if (a.resid) v += a.resid[(long long)(m % a.res_rows) * a.ldr + n];
+        if (a.mask && !(a.mask[(long long)m * a.ldm + n] > 0.f)) v = 0.f;
+        a.C[(long long)m * a.ldc + n] = v;
+      }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int cm_gemm_h3(const float* a, long long lda, int trans_a, const float* b, long long ldb, int trans_b, float* c,
+               long long ldc, const float* bias, const float* resid, long long ldr, int res_rows, const float* mask,
+               long long ldm, int relu, int m, int n, int k, int ksplit, cm_stream stream) {
+  if (m <= 0 || n <= 0 || k <= 0 || !a || !b || !c || lda <= 0 || ldb <= 0 || ldc < n) return -22;
+  if (ksplit < 1) ksplit = 1;
+  if (ksplit > 1 && (resid || mask || relu)) return -22;      // split K accumulates raw sums into a zeroed C
+  if (resid && (res_rows <= 0 || ldr < n)) return -22;
+  if (mask && ldm < n) return -22;
+  GemmArgs g;
+  g.A = a; g.B = b; g.C = c; g.bias = bias; g.resid = resid; g.mask = mask;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.ldm = ldm;
+  g.M = m; g.N = n; g.K = k; g.res_rows = res_rows > 0 ? res_rows : m; g.relu = relu;
+  const int nstage = cdiv(k, GBK);
+  g.ksplit = ksplit > nstage ? nstage : ksplit;
+  const dim3 grid(cdiv(n, GBN), cdiv(m, GBM), g.ksplit);
+  hipStream_t st = (hipStream_t)stream;
+  if (!trans_a && !trans_b) gemm_h3_kernel<false, false><<<grid, 256, 0, st>>>(g);
+  else if (!trans_a && trans_b) gemm_h3_kernel<false, true><<<grid, 256, 0, st>>>(g);
+  else if (trans_a && trans_b) gemm_h3_kernel<true, true><<<grid, 256, 0, st>>>(g);
+  else gemm_h3_kernel<true, false><<<grid, 256, 0, st>>>(g);
+  CM_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -11,8 +11,8 @@ both ways, and the same default initialisation under ``torch.manual_seed``): the
 tensors to the engine (HIP kernels) through one ``autograd.Function`` so that the harness's ``loss.backward()``
 works unchanged.  There is no CPU path for these classes: a CPU input raises ``RuntimeError``.
 
-``SimpleCNN`` (BASELINE.json configs[0], "CPU plumbing, no GPU") and, until its attention kernels exist,
-``cnn_transformer`` are stock-torch modules from ``host_models.py``.
+``cnn_transformer`` (BASELINE.json configs[3]) lives in ``cnn_transformer.py`` (HIP path as well); ``SimpleCNN``
+(configs[0], "CPU plumbing, no GPU") is the stock-torch module of ``host_models.py``.
 """
 from typing import Dict, List
 
@@ -276,7 +276,8 @@ def get_model(cfg):
 
       * ``unet_convlstm_attention`` -> AttUNetConvLSTM on the HIP engine (the hot path);
       * ``unet``                    -> UNet on the HIP engine (same kernels, single frame);
-      * ``cnn_transformer``         -> CNNTransformer, stock torch for now (host_models.py; no HIP attention path yet);
+      * ``cnn_transformer``         -> CNNTransformer on the HIP path (cnn_transformer.py: fp16x3 GEMMs, attention,
+                                       LayerNorm kernels; dropout-free function, see that module);
       * ``SimpleCNN``               -> the stock-torch SimpleCNN (BASELINE configs[0]: "CPU PyTorch, plumbing").
 
     Differences from the reference, both deliberate: for ``unet_convlstm_attention`` ``in_ch`` is
@@ -296,7 +297,7 @@ def get_model(cfg):
         kwargs = {k: v for k, v in _items(cfg.model) if k != "type"}      # src/models.py:9-13
         return SimpleCNN(n_input_channels=n_in, n_output_channels=n_out, **kwargs)
     if mtype == "cnn_transformer":
-        from .host_models import CNNTransformer
+        from .cnn_transformer import CNNTransformer
         return CNNTransformer(in_channels=n_in, out_channels=n_out, embed_dim=int(cfg.model.embed_dim),
                               depth=int(cfg.model.depth), n_heads=int(cfg.model.n_heads),
                               mlp_dim=int(cfg.model.mlp_dim), dropout=float(cfg.model.dropout))

@@ -539,3 +539,87 @@ def head_mse_bwd(x, w, b, y, loss, dw, db, pred_out=None):
 def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):
     check(lib.cm_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
                            grad_scale, _stream()), "adam")
+
+
+# ----------------------------------------------------------------------------------------------------- cnn_transformer
+def gemm(a, b, m, n, k, trans_a=False, trans_b=False, bias=None, resid=None, res_rows=0, mask=None, relu=False,
+         out=None, ksplit=1, lda=None, ldb=None):
+    """out[m, n] = relu?(op(a) op(b) + bias) + resid (masked) on the fp16x3 GEMM kernel (cm_gemm_h3).  a / b are 2-D
+    row-major tensors: a is [m, k] (or [k, m] when trans_a), b is [n, k] -- an nn.Linear weight, out = a b^T -- (or
+    [k, n] when trans_b).  ksplit > 1 ACCUMULATES into ``out`` (which the caller zeroed)."""
+    if out is None:
+        out = torch.empty(m, n, device=a.device, dtype=torch.float32)
+    lda = a.stride(0) if lda is None else lda
+    ldb = b.stride(0) if ldb is None else ldb
+    check(lib.cm_gemm_h3(_p(a), lda, int(trans_a), _p(b), ldb, int(trans_b), _p(out), out.stride(0), _p(bias), _p(resid),
+                         0 if resid is None else resid.stride(0), res_rows, _p(mask),
+                         0 if mask is None else mask.stride(0), int(relu), m, n, k, ksplit, _stream()), "gemm_h3")
+    return out
+
+
+def layernorm_fwd(x, resid, gamma, beta, eps=1e-5):
+    m, e = x.shape
+    s = torch.empty_like(x)
+    y = torch.empty_like(x)
+    stats = torch.empty(m, 2, device=x.device, dtype=torch.float32)
+    check(lib.cm_layernorm_fwd(_p(_contig(x)), _p(resid), _p(gamma), _p(beta), _p(s), _p(y), _p(stats), m, e, eps,
+                               _stream()), "layernorm_fwd")
+    return y, s, stats
+
+
+def layernorm_bwd(s, stats, gamma, dy, dgamma, dbeta):
+    m, e = s.shape
+    ds = torch.empty_like(s)
+    check(lib.cm_layernorm_bwd(_p(s), _p(stats), _p(gamma), _p(_contig(dy)), _p(ds), _p(dgamma), _p(dbeta), m, e,
+                               _stream()), "layernorm_bwd")
+    return ds
+
+
+def attention_fwd(qkv, b, s, e, h):
+    p = torch.empty(b, h, s, s, device=qkv.device, dtype=torch.float32)
+    o = torch.empty(b * s, e, device=qkv.device, dtype=torch.float32)
+    check(lib.cm_attention_fwd(_p(_contig(qkv)), _p(p), _p(o), b, s, e, h, _stream()), "attention_fwd")
+    return p, o
+
+
+def attention_bwd(qkv, p, d_o, b, s, e, h):
+    scratch = torch.empty_like(p)
+    dqkv = torch.empty_like(qkv)
+    check(lib.cm_attention_bwd(_p(qkv), _p(p), _p(_contig(d_o)), _p(scratch), _p(dqkv), b, s, e, h, _stream()),
+          "attention_bwd")
+    return dqkv
+
+
+def im2col_s2(x, b, cin, h, w, ldc, tokens_in):
+    col = torch.empty(b * (h // 2) * (w // 2), ldc, device=x.device, dtype=torch.float32)
+    check(lib.cm_im2col_s2(_p(_contig(x)), _p(col), b, cin, h, w, ldc, int(tokens_in), _stream()), "im2col_s2")
+    return col
+
+
+def col2im_s2(dcol, b, cin, h, w):
+    dx = torch.empty(b * h * w, cin, device=dcol.device, dtype=torch.float32)
+    check(lib.cm_col2im_s2(_p(dcol), _p(dx), b, cin, h, w, dcol.stride(0), _stream()), "col2im_s2")
+    return dx
+
+
+def transpose_batched(x, batch, rows, cols):
+    out = torch.empty(batch, cols, rows, device=x.device, dtype=torch.float32)
+    check(lib.cm_transpose_batched(_p(_contig(x)), _p(out), batch, rows, cols, _stream()), "transpose")
+    return out
+
+
+def relu_(x):
+    check(lib.cm_relu(_p(x), x.numel(), _stream()), "relu")
+    return x
+
+
+def relu_mask_(g, y):
+    check(lib.cm_relu_mask(_p(g), _p(y), g.numel(), _stream()), "relu_mask")
+    return g
+
+
+def rowgroup_sum(x, out, period=1):
+    """out[r % period, c] += sum_r x[r, c]  (x 2-D contiguous)."""
+    rows, cols = x.shape
+    check(lib.cm_rowgroup_sum(_p(_contig(x)), _p(out), rows, cols, period, _stream()), "rowgroup_sum")
+    return out

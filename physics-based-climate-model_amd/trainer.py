@@ -72,7 +72,8 @@ class HotPathTrainer:
         pk = plan.pack()
         _, sv = self.model._engine_forward(p, pk, x, save=True, head=False)
         # output head + MSE + the head's backward: one pass over the last decoder activation
-        dd1 = ops.head_mse_bwd(sv.d1, p["head.weight"], p["head.bias"], y, self.loss, g["head.weight"], g["head.bias"])
+        hw, hb = getattr(self.model, "_head_param_names", ("head.weight", "head.bias"))
+        dd1 = ops.head_mse_bwd(sv.d1, p[hw], p[hb], y, self.loss, g[hw], g[hb])
         if self.keep_saved:
             self.saved = sv
         if phase == "early":

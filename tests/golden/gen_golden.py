@@ -327,8 +327,14 @@ def main():
     net.eval()                          # dropout off: deterministic forward
     xg = x.clone().requires_grad_()
     yv = net(xg); yv.square().mean().backward()
-    npz("cnn_transformer_tiny.npz", names=np.array(names), sums=np.array(sums), x=x, y_eval=yv, dx=xg.grad,
-        g_pos=net.pos_embedding.grad, g_inproj0=net.transformer.layers[0].self_attn.in_proj_weight.grad)
+    arrs = dict(names=np.array(names), sums=np.array(sums), x=x, y_eval=yv, dx=xg.grad,
+                g_pos=net.pos_embedding.grad, g_inproj0=net.transformer.layers[0].self_attn.in_proj_weight.grad,
+                cfg=np.array([5, 2, 32, 2, 4, 48]))
+    for k, v in net.state_dict().items():
+        arrs["p." + k] = v.clone()
+    for k, p_ in net.named_parameters():
+        arrs["g." + k] = p_.grad.clone()
+    npz("cnn_transformer_tiny.npz", **arrs)
     net = ct.CNNTransformer(in_channels=5, out_channels=2, embed_dim=256, depth=6, n_heads=8, mlp_dim=256, dropout=0.1)
     npz("cnn_transformer_cfg4.npz", n_params=np.array(sum(p_.numel() for p_ in net.parameters())),
         names=np.array(list(net.state_dict().keys())))

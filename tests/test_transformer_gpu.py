@@ -1,0 +1,180 @@
+"""cnn_transformer on the MI355X (BASELINE.json configs[3]; reference src/cnn_transformer.py:4-54): every new launcher
+against float64 torch, the whole model against the reference's fixture and the CPU oracle.  Tolerance 1e-4 rel L2."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+from conftest import load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from climate_amd import ops as o
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator("cpu").manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("m,n,k", [(256, 128, 64), (300, 70, 45), (13, 200, 130), (1024, 768, 256), (129, 129, 33)])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True), (True, False)])
+def test_gemm_fp16x3_all_layouts(ops, m, n, k, ta, tb):
+    a = rnd(m, k, seed=1); b = rnd(n, k, seed=2, scale=k ** -0.5)
+    ref = a.double() @ b.double().t()
+    A = (a.t().contiguous() if ta else a).cuda()
+    Bm = (b.t().contiguous() if tb else b).cuda()
+    c = ops.gemm(A, Bm, m, n, k, trans_a=ta, trans_b=tb)
+    assert rel_l2(c, ref) < 2e-6
+    bias = rnd(n, seed=3); res = rnd(7, n, seed=4); msk = rnd(m, n, seed=5)
+    c2 = ops.gemm(A, Bm, m, n, k, trans_a=ta, trans_b=tb, bias=bias.cuda(), relu=True, resid=res.cuda(), res_rows=7,
+                  mask=msk.cuda())
+    want = torch.relu(ref + bias.double()) + res.double()[torch.arange(m) % 7]
+    want = torch.where(msk.double() > 0, want, torch.zeros_like(want))
+    assert rel_l2(c2, want) < 2e-6
+    for ks in (2, 5, 64):
+        acc = torch.zeros(m, n, device="cuda")
+        ops.gemm(A, Bm, m, n, k, trans_a=ta, trans_b=tb, out=acc, ksplit=ks)
+        ops.gemm(A, Bm, m, n, k, trans_a=ta, trans_b=tb, out=acc, ksplit=ks)
+        assert rel_l2(acc, 2 * ref) < 2e-6, ks
+
+
+@pytest.mark.parametrize("amag,bmag", [(1e-9, 1.0), (3e7, 1e-6), (1e-18, 1e-14), (1e12, 1e9)])
+def test_gemm_fp16x3_any_magnitude(ops, amag, bmag):
+    m, n, k = 200, 150, 300
+    a = rnd(m, k, seed=6) * amag; b = rnd(n, k, seed=7) * bmag
+    a[:, 64:128] *= 1e-4                       # the running maxima move between K stages
+    b[:, 200:] *= 1e3
+    ref = a.double() @ b.double().t()
+    c = ops.gemm(a.cuda(), b.cuda(), m, n, k)
+    assert torch.isfinite(c).all() and rel_l2(c, ref) < 2e-6
+
+
+@pytest.mark.parametrize("m,e", [(37, 32), (216, 256), (50, 100), (9, 1000)])
+def test_layernorm(ops, m, e):
+    x = rnd(m, e, seed=8); r = rnd(m, e, seed=9); g = 1 + 0.2 * rnd(e, seed=10); b = 0.1 * rnd(e, seed=11)
+    dy = rnd(m, e, seed=12)
+    xd = x.double().requires_grad_(); rd = r.double().requires_grad_()
+    gd = g.double().requires_grad_(); bd = b.double().requires_grad_()
+    ref = F.layer_norm(xd + rd, (e,), gd, bd, 1e-5); ref.backward(dy.double())
+    y, s, st = ops.layernorm_fwd(x.cuda(), r.cuda(), g.cuda(), b.cuda())
+    assert rel_l2(y, ref) < TOL and rel_l2(s, (x + r).double()) < 1e-6
+    dg = torch.zeros(e, device="cuda"); db = torch.zeros(e, device="cuda")
+    ds = ops.layernorm_bwd(s, st, g.cuda(), dy.cuda(), dg, db)
+    assert rel_l2(ds, xd.grad) < TOL and rel_l2(dg, gd.grad) < TOL and rel_l2(db, bd.grad) < TOL
+
+
+@pytest.mark.parametrize("b,s,e,h", [(2, 216, 256, 8), (3, 216, 32, 4), (1, 50, 64, 4), (2, 256, 64, 2)])
+def test_attention(ops, b, s, e, h):
+    d = e // h
+    qkv = rnd(b * s, 3 * e, seed=13)
+    do = rnd(b * s, e, seed=14)
+    qd = qkv.double().requires_grad_()
+    q, k, v = (z.reshape(b, s, h, d).transpose(1, 2) for z in qd.chunk(3, dim=-1))
+    att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(d), dim=-1)
+    ref = (att @ v).transpose(1, 2).reshape(b * s, e)
+    ref.backward(do.double())
+    P, o = ops.attention_fwd(qkv.cuda(), b, s, e, h)
+    assert rel_l2(o, ref) < TOL and rel_l2(P, att) < TOL
+    dqkv = ops.attention_bwd(qkv.cuda(), P, do.cuda(), b, s, e, h)
+    assert rel_l2(dqkv, qd.grad) < TOL
+
+
+@pytest.mark.parametrize("b,c,h,w", [(2, 5, 48, 72), (3, 16, 8, 12), (1, 64, 24, 36)])
+def test_im2col_col2im_stride2(ops, b, c, h, w):
+    x = rnd(b, c, h, w, seed=15)
+    ldc = (c * 9 + 3) // 4 * 4
+    col = ops.im2col_s2(x.cuda(), b, c, h, w, ldc, tokens_in=False)
+    ref = F.unfold(x, 3, padding=1, stride=2).transpose(1, 2).reshape(b * (h // 2) * (w // 2), c * 9)
+    assert torch.equal(col[:, :c * 9].cpu(), ref) and (col[:, c * 9:] == 0).all()
+    xt = x.permute(0, 2, 3, 1).contiguous().view(b * h * w, c)
+    col2 = ops.im2col_s2(xt.cuda(), b, c, h, w, ldc, tokens_in=True)
+    assert torch.equal(col2.cpu(), col.cpu())
+    dcol = rnd(b * (h // 2) * (w // 2), ldc, seed=16)
+    want = F.fold(dcol[:, :c * 9].double().reshape(b, -1, c * 9).transpose(1, 2), (h, w), 3, padding=1, stride=2)
+    got = ops.col2im_s2(dcol.cuda(), b, c, h, w).view(b, h, w, c).permute(0, 3, 1, 2)
+    assert rel_l2(got, want) < 1e-6
+
+
+def test_small_helpers(ops):
+    x = rnd(3, 50, 70, seed=17)
+    assert torch.equal(ops.transpose_batched(x.cuda(), 3, 50, 70).cpu(), x.transpose(1, 2).contiguous())
+    y = rnd(1000, seed=18).cuda()
+    g = rnd(1000, seed=19).cuda()
+    want = torch.where(y > 0, g, torch.zeros_like(g))
+    assert torch.equal(ops.relu_mask_(g.clone(), y), want)
+    assert torch.equal(ops.relu_(y.clone()), torch.relu(y))
+    t = rnd(64 * 216, 96, seed=20)
+    cs = torch.zeros(1, 96, device="cuda"); ps = torch.zeros(216, 96, device="cuda")
+    ops.rowgroup_sum(t.cuda(), cs); ops.rowgroup_sum(t.cuda(), ps, period=216)
+    assert rel_l2(cs, t.double().sum(0, keepdim=True)) < 1e-6
+    assert rel_l2(ps, t.double().view(64, 216, 96).sum(0)) < 1e-6
+
+
+def test_cnn_transformer_vs_reference_fixture(ops):
+    """Whole model (embed 32, depth 2, 4 heads, mlp 48) vs the reference: forward, d(input), all 35 gradients."""
+    from climate_amd.cnn_transformer import CNNTransformer
+    g = load_golden("cnn_transformer_tiny.npz")
+    cin, cout, e, depth, heads, mlp = (int(v) for v in g["cfg"])
+    m = CNNTransformer(cin, cout, e, depth, heads, mlp, dropout=0.1)
+    m.load_state_dict({k[2:]: v for k, v in g.items() if k.startswith("p.")})
+    m = m.cuda().eval()                                   # the fixture is the dropout-free function
+    x = g["x"].cuda().requires_grad_()
+    y = m(x)
+    assert rel_l2(y, g["y_eval"]) < TOL
+    y.square().mean().backward()
+    assert rel_l2(x.grad, g["dx"]) < TOL
+    named = dict(m.named_parameters())
+    worst = 0.0
+    for k, v in g.items():
+        if k.startswith("g."):
+            err = rel_l2(named[k[2:]].grad, v)
+            worst = max(worst, err)
+            assert err < TOL, (k, err)
+    print(f"cnn_transformer tiny: worst grad rel-L2 {worst:.2e}")
+    m.train()
+    with pytest.raises(RuntimeError, match="dropout"):
+        m(x)
+
+
+def test_cnn_transformer_config4_width_vs_oracle(ops):
+    """BASELINE config 4's widths (embed 256, 8 heads -> head_dim 32, mlp 256, 216 tokens), depth 2, batch 3, vs the CPU
+    oracle in float64; then three fused Adam steps through the hipGraph trainer (dropout 0) vs torch.optim.Adam."""
+    from climate_amd.cnn_transformer import CNNTransformer
+    from climate_amd.trainer import HotPathTrainer
+    torch.manual_seed(3)
+    m = CNNTransformer(5, 2, 256, 2, 8, 256, dropout=0.0)
+    P = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.cuda()
+    gen = torch.Generator("cpu").manual_seed(4)
+    x = torch.randn(3, 5, 48, 72, generator=gen); y = torch.randn(3, 2, 48, 72, generator=gen)
+    pd = {k: v.double().requires_grad_() for k, v in P.items()}
+    lo = F.mse_loss(oracle.cnn_transformer_forward(pd, x.double(), 8), y.double()); lo.backward()
+    pred = m(x.cuda()); lg = F.mse_loss(pred, y.cuda()); lg.backward()
+    assert abs(lg.item() - lo.item()) < 1e-5 * lo.item()
+    named = dict(m.named_parameters())
+    for k in pd:
+        assert rel_l2(named[k].grad, pd[k].grad) < TOL, k
+    # fused trainer: 3 Adam steps vs the oracle + torch.optim.Adam (fp32)
+    pf = {k: v.clone().requires_grad_() for k, v in P.items()}
+    opt = torch.optim.Adam(list(pf.values()), lr=5e-4)
+    m2 = CNNTransformer(5, 2, 256, 2, 8, 256, dropout=0.0)
+    m2.load_state_dict(P)
+    tr = HotPathTrainer(m2.cuda(), lr=5e-4, use_graph=True, distributed=False)
+    for step in range(3):
+        opt.zero_grad()
+        l_ref = F.mse_loss(oracle.cnn_transformer_forward(pf, x, 8), y); l_ref.backward(); opt.step()
+        l_hip = tr.step(x.cuda(), y.cuda()).item()
+        assert abs(l_hip - l_ref.item()) < 2e-5 * l_ref.item(), step
+    sd = m2.state_dict()
+    for k in pf:
+        assert rel_l2(sd[k], pf[k]) < 1e-4, k
