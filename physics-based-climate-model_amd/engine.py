@@ -138,10 +138,10 @@ class Plan:
                 hsz.append(lib.cm_conv3x3_h3_packed_bytes(w.shape[0] if dg else cin, cin if dg else w.shape[0]) // 4)
             self.wph_arena = torch.empty(sum(hsz), device=dev, dtype=torch.float32)
             rec, o, blk = [], 0, 0
+            self._winv_slot = {}
             for j, ((key, name, off, cin, dg), sz) in enumerate(zip(jobs, hsz)):
                 w = p[name]
                 self.pkh[key] = self.wph_arena[o:o + sz]
-                self._winv_slot = getattr(self, "_winv_slot", {})
                 self._winv_slot[key] = j
                 rec.append([w.data_ptr(), self.pkh[key].data_ptr(), w.shape[0], w.shape[1], off, cin, dg, blk])
                 blk += max(1, min(512, (sz // 8 + 255) // 256))
