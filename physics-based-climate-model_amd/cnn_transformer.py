@@ -78,8 +78,9 @@ def forward(p: Dict[str, Tensor], x: Tensor, n_heads: int, save: bool = True, he
     sv = None
     if save:
         sv = _Saved()
-        sv.shape, sv.col1, sv.y1, sv.col2, sv.t0, sv.layers, sv.z, sv.d1, sv.d2 = (B, Cin, H, W), col1, y1, col2, t0, layers, z, d1, d2
-        sv.d1_head = d2                   # input of the 1x1 head (the fused trainer's head+MSE launch reads it)
+        sv.shape, sv.col1, sv.y1, sv.col2, sv.t0, sv.layers, sv.z = (B, Cin, H, W), col1, y1, col2, t0, layers, z
+        sv.dec1, sv.dec2 = d1, d2         # decoder activations (post-ReLU)
+        sv.d1 = d2                        # input of the 1x1 head: what the fused trainer's head+MSE launch reads
     return pred, sv
 
 
@@ -106,10 +107,10 @@ def backward(p: Dict[str, Tensor], g: Dict[str, Tensor], sv, n_heads: int, dpred
     E2, E = p["encoder.0.weight"].shape[0], p["encoder.2.weight"].shape[0]
     M1, M = B * (H // 2) * (W // 2), B * S
     if dd_head is None:
-        dd_head = ops.head_bwd(dpred, sv.d2, p["decoder.4.weight"], g["decoder.4.weight"], g["decoder.4.bias"])
-    dd2 = ops.relu_mask_(dd_head, sv.d2)
-    dd1 = ops.relu_mask_(ops.convT2x2_bwd(sv.d1, p["decoder.2.weight"], dd2, g["decoder.2.weight"], g["decoder.2.bias"]),
-                         sv.d1)
+        dd_head = ops.head_bwd(dpred, sv.dec2, p["decoder.4.weight"], g["decoder.4.weight"], g["decoder.4.bias"])
+    dd2 = ops.relu_mask_(dd_head, sv.dec2)
+    dd1 = ops.relu_mask_(ops.convT2x2_bwd(sv.dec1, p["decoder.2.weight"], dd2, g["decoder.2.weight"],
+                                          g["decoder.2.bias"]), sv.dec1)
     dz = ops.convT2x2_bwd(sv.z, p["decoder.0.weight"], dd1, g["decoder.0.weight"], g["decoder.0.bias"])
     dt = ops.transpose_batched(dz.view(B, E, S), B, E, S).view(M, E)
     for i in range(len(sv.layers) - 1, -1, -1):
@@ -181,10 +182,7 @@ class CNNTransformer(_HipModule):
 
     def _engine_forward(self, p, pk, x, save=True, head=True):
         self._check_dropout()
-        pred, sv = forward(p, x, self.n_heads, save=save, head=head)
-        if sv is not None:
-            sv.d1 = sv.d1_head
-        return pred, sv
+        return forward(p, x, self.n_heads, save=save, head=head)
 
     def _engine_backward(self, p, pk, g, sv, dpred, need_dx=False, dd1=None):
         return backward(p, g, sv, self.n_heads, dpred=dpred, dd_head=dd1, need_dx=need_dx)
