@@ -177,4 +177,11 @@ def test_cnn_transformer_config4_width_vs_oracle(ops):
         assert abs(l_hip - l_ref.item()) < 2e-5 * l_ref.item(), step
     sd = m2.state_dict()
     for k in pf:
-        assert rel_l2(sd[k], pf[k]) < 1e-4, k
+        got, want = sd[k], pf[k]
+        if k.endswith("self_attn.in_proj_bias"):
+            # the KEY third of the bias has an identically zero true gradient (softmax is invariant to a constant added
+            # to a row's scores), so its computed gradient is rounding noise and Adam's per-element normalisation turns
+            # the noise's sign into lr-sized steps in BOTH implementations: not a comparable quantity.  q and v thirds:
+            e = got.numel() // 3
+            got, want = torch.cat([got[:e], got[2 * e:]]), torch.cat([want[:e], want[2 * e:]])
+        assert rel_l2(got, want) < 1e-4, k
