@@ -164,39 +164,47 @@ def test_cnn_transformer_config4_width_vs_oracle(ops):
     named = dict(m.named_parameters())
     for k in pd:
         assert rel_l2(named[k].grad, pd[k].grad) < TOL, k
-    # fused trainer: 3 Adam steps vs the oracle + torch.optim.Adam, both in FLOAT64 (so that the error is the device's)
-    pf = {k: v.double().clone().requires_grad_() for k, v in P.items()}
-    opt = torch.optim.Adam(list(pf.values()), lr=5e-4)
+    # fused trainer: three Adam steps through the hipGraph.  Trajectories of two implementations are not compared
+    # parameter by parameter (tools/tf_probe.py: by the third step the float64 oracle's OWN gradient moves by 1.7e-3 when
+    # its parameters are perturbed by the 1e-6 that Adam's g / (|g| + eps) makes out of rounding noise on elements with
+    # |g| ~ eps); instead every step is checked in two well-conditioned halves:
+    #   (1) the gradient the graph produced == the float64 oracle's gradient AT THE DEVICE'S parameters of that step;
+    #   (2) the parameters after the step == torch.optim.Adam (float64) fed with the device's gradients.
     m2 = CNNTransformer(5, 2, 256, 2, 8, 256, dropout=0.0)
     m2.load_state_dict(P)
     tr = HotPathTrainer(m2.cuda(), lr=5e-4, use_graph=True, distributed=False)
-    for step in range(3):
-        opt.zero_grad()
-        l_ref = F.mse_loss(oracle.cnn_transformer_forward(pf, x.double(), 8), y.double()); l_ref.backward(); opt.step()
-        l_hip = tr.step(x.cuda(), y.cuda()).item()
-        assert abs(l_hip - l_ref.item()) < 2e-5 * l_ref.item(), step
-    # Adam's first moment is linear in the gradients: the well-conditioned check of three steps of gradients + optimizer
-    st = tr.optimizer_state_dict()["state"]
     names = [n for n, _ in m2.named_parameters()]
-    worst = 0.0
-    for i, k in enumerate(names):
-        ref_m = opt.state[pf[k]]["exp_avg"]
-        got_m = st[i]["exp_avg"]
-        if k.endswith("self_attn.in_proj_bias"):
-            # the KEY third of the bias has an identically zero true gradient (softmax is invariant to a constant added
-            # to a row's scores): what is computed there is rounding noise in any implementation
-            e = got_m.numel() // 3
-            got_m, ref_m = torch.cat([got_m[:e], got_m[2 * e:]]), torch.cat([ref_m[:e], ref_m[2 * e:]])
-        err = rel_l2(got_m, ref_m)
-        worst = max(worst, err)
-        assert err < TOL, (k, err)
-    print(f"cnn_transformer config-4 widths, 3 fused Adam steps: worst first-moment rel-L2 {worst:.2e}")
-    # parameters: Adam's per-element normalisation m / sqrt(v) amplifies relative gradient noise of elements whose
-    # gradient nearly cancels; the loss trajectory above and the first moments pin the step, the parameters are
-    # checked where they moved by a full step
-    sd = m2.state_dict()
-    for k in names:
-        got, want = sd[k].cpu().double(), pf[k].detach()
-        moved = (want - P[k].double()).abs() > 1.2e-3          # ~ 3 steps of lr 5e-4 in a consistent direction
-        if moved.any():
-            assert rel_l2(got[moved], want[moved]) < TOL, k
+    pa = {k: P[k].double().clone().requires_grad_() for k in names}
+    opt = torch.optim.Adam([pa[k] for k in names], lr=5e-4)
+    worst_g = worst_p = 0.0
+    for step in range(3):
+        pd = {k: v.detach().cpu().double().requires_grad_() for k, v in m2.state_dict().items()}
+        l_ref = F.mse_loss(oracle.cnn_transformer_forward(pd, x.double(), 8), y.double()); l_ref.backward()
+        l_hip = tr.step(x.cuda(), y.cuda()).item()
+        assert abs(l_hip - l_ref.item()) < 1e-5 * l_ref.item(), step
+        gdev = tr.grad.detach().cpu().double()
+        off = 0
+        for k in names:
+            n = pa[k].numel()
+            g = gdev[off:off + n].view(pa[k].shape); off += n
+            want = pd[k].grad
+            if k.endswith("self_attn.in_proj_bias"):
+                # the KEY third has an identically zero true gradient (softmax is invariant to a constant added to a
+                # row's scores): what any implementation computes there is rounding noise
+                e = n // 3
+                assert g[e:2 * e].abs().max() < 1e-6 * want.abs().max(), (k, step)
+                err = rel_l2(torch.cat([g[:e], g[2 * e:]]), torch.cat([want[:e], want[2 * e:]]))
+            else:
+                err = rel_l2(g, want)
+            worst_g = max(worst_g, err)
+            assert err < TOL, (k, step, err)
+            pa[k].grad = g.clone()
+        assert off <= gdev.numel() and not gdev[off:].any()      # the flat buffer's alignment tail
+        opt.step()
+        sd = m2.state_dict()
+        for k in names:
+            err = rel_l2(sd[k], pa[k].detach())
+            worst_p = max(worst_p, err)
+            assert err < 1e-5, (k, step, err)
+    print(f"cnn_transformer config-4 widths, 3 fused Adam steps: worst gradient rel-L2 {worst_g:.2e}, "
+          f"worst parameter rel-L2 vs float64 Adam on the same gradients {worst_p:.2e}")
