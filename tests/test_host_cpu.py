@@ -136,7 +136,8 @@ def test_factory_serves_every_reference_model_type():
 
 def test_cnn_transformer_matches_reference():
     """model.type = cnn_transformer (src/cnn_transformer.py:4-54; BASELINE configs[3]): same state_dict, default init
-    under a seed, eval forward and gradients as the reference (stock torch: not on the HIP path yet)."""
+    under a seed, eval forward and gradients as the reference -- for the stock-torch restatement (host_models) and, as
+    far as a CPU can see (names, shapes, initial values, constructor checks), for the HIP module ``get_model`` serves."""
     import climate_amd
     from climate_amd.config import load_config
     from climate_amd.host_models import CNNTransformer
@@ -159,8 +160,19 @@ def test_cnn_transformer_matches_reference():
                                 overrides=["model=cnn_transformer", "model.embed_dim=256", "model.depth=6",
                                            "model.n_heads=8"]))
     c4 = load_golden("cnn_transformer_cfg4.npz")
-    assert isinstance(big, CNNTransformer) and list(big.state_dict()) == c4["names"].tolist()
+    from climate_amd.cnn_transformer import CNNTransformer as HipCNNTransformer
+    assert isinstance(big, HipCNNTransformer) and list(big.state_dict()) == c4["names"].tolist()
     assert sum(p.numel() for p in big.parameters()) == int(c4["n_params"]) == 2895170
+    with pytest.raises(RuntimeError, match="HIP path only"):
+        big(torch.zeros(1, 5, 48, 72))
+    # same constructor, same draws from the global generator, same state_dict as the reference's module
+    torch.manual_seed(42)
+    h = HipCNNTransformer(in_channels=5, out_channels=2, embed_dim=32, depth=2, n_heads=4, mlp_dim=48, dropout=0.1)
+    assert list(h.state_dict()) == g["names"].tolist()
+    for k in sd:
+        assert torch.equal(h.state_dict()[k], sd[k]), k
+    with pytest.raises(ValueError, match="head_dim"):
+        HipCNNTransformer(embed_dim=128, n_heads=2)
 
 
 def test_simple_cnn_matches_reference():
