@@ -7,8 +7,9 @@
 // GroupNorm from the SE / spatial-gate backward maps on the fly (see attention_gates.hip), so the full-size
 // d(a2) tensor is never materialised.
 //
-// All passes are HBM/L2 streaming passes; statistics use a two-pass (mean, then centred sum of squares) scheme in
-// fp32 so they stay within ~1e-7 of torch's CPU result.
+// All passes are HBM/L2 streaming passes; statistics are fp32 sums about a point close to the mean (a true two-pass in
+// the register-resident kernels, a sample-mean pivot in the streaming ones) so they stay within ~1e-7 of torch's CPU
+// result.
 #include <stdlib.h>
 #include "common.h"
 #include "se_wgrad.h"
@@ -62,9 +63,11 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_kernel(const float* __
   float* yg = y + base;
   const int tid = threadIdx.x;
 
-  // one statistics pass: sums of (x - pivot) and (x - pivot)^2 with the group's first element as pivot (keeps the
-  // E[d^2] - E[d]^2 cancellation harmless); the apply pass then re-reads the group from L2
-  const float pivot = xg[0];
+  // one statistics pass: sums of (x - pivot) and (x - pivot)^2.  The pivot is the mean of a 256-element sample spread
+  // over the whole group, i.e. within ~sigma/16 of the group mean, so E[d^2] - E[d]^2 does not cancel (a single
+  // element as pivot -- e.g. the zero-padded corner pixel -- can sit many sigma out, which cost 10x in the error of
+  // rstd: tools/noise_probe.py).  The apply pass then re-reads the group from L2.
+  const float pivot = block_sum(xg[(long long)tid * L / GN_THREADS], red) * (1.f / GN_THREADS);
   float s1 = 0.f, s2 = 0.f;
   if (VEC) {
     const float4* x4 = reinterpret_cast<const float4*>(xg);
@@ -294,24 +297,33 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_reg_kernel(const float
   const float4* xg = reinterpret_cast<const float4*>(x + base);
   float4* yg = reinterpret_cast<float4*>(y + base);
   if (tid < 64) psum[tid] = 0.f;
+  // the group is register resident, so the statistics are a true two-pass: the mean first (sums shifted by the first
+  // element, only to keep them small), then the sum of squares about that mean (with the usual first-order correction)
   const float pivot = x[base];
   float4 v[MAXQ];
-  float s1 = 0.f, s2 = 0.f;
+  float s1 = 0.f;
 #pragma unroll
   for (int q = 0; q < MAXQ; ++q) {
     const int r = wave + q * NW;
     const int cl = r / RPC, i = (r % RPC) * 64 + lane;
     const bool ok = r < rows && i < HWV;
     v[q] = ok ? xg[(long long)cl * HWV + i] : make_float4(pivot, pivot, pivot, pivot);
-    const float a = v[q].x - pivot, b = v[q].y - pivot, c = v[q].z - pivot, d = v[q].w - pivot;
-    s1 += (a + b) + (c + d);
-    s2 += (a * a + b * b) + (c * c + d * d);
+    s1 += ((v[q].x - pivot) + (v[q].y - pivot)) + ((v[q].z - pivot) + (v[q].w - pivot));
   }
   const float L = (float)(cpg * HW);
-  s1 = block_sum(s1, red) / L;
+  const float mean = pivot + block_sum(s1, red) / L;
+  float s2 = 0.f, s1c = 0.f;
+#pragma unroll
+  for (int q = 0; q < MAXQ; ++q) {
+    const int r = wave + q * NW;
+    const bool ok = r < rows && (r % RPC) * 64 + lane < HWV;
+    const float a = v[q].x - mean, b = v[q].y - mean, c = v[q].z - mean, d = v[q].w - mean;
+    s1c += ok ? (a + b) + (c + d) : 0.f;
+    s2 += ok ? (a * a + b * b) + (c * c + d * d) : 0.f;
+  }
+  s1c = block_sum(s1c, red) / L;
   s2 = block_sum(s2, red) / L;
-  const float mean = pivot + s1;
-  const float rstd = rsqrtf(fmaxf(s2 - s1 * s1, 0.f) + eps);
+  const float rstd = rsqrtf(fmaxf(s2 - s1c * s1c, 0.f) + eps);
   if (tid == 0) {
     stats[2 * blockIdx.x] = mean;
     stats[2 * blockIdx.x + 1] = rstd;

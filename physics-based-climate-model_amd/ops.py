@@ -112,6 +112,7 @@ def pack_conv3x3(w, c_off=0, cin=None, dgrad=False):
 
 SPLIT_BASE = 1 << 20   # tuned configuration ids >= SPLIT_BASE select the bf16x6 kernel (cm_conv3x3_split)
 H3_BASE = 1 << 21      # ... ids >= H3_BASE the fp16x3 kernel (cm_conv3x3_h3 / cm_wgrad3x3_h3)
+ACC_CHANNELS = int(os.environ.get("CM_ACC_CHANNELS", "128"))   # see conv3x3: longest reduction one accumulator takes
 SMALLC_CFG = 1 << 22   # tuned configuration id of the few-input-channels kernels (cm_conv3x3_smallc / cm_wgrad3x3_smallc)
 LAST_CONV_CONFIG = -1   # configuration the most recent conv3x3() call ran with (the engine prunes unused weight packs)
 
@@ -164,6 +165,15 @@ def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1, w
         use_h3 = wph is not None and (c1 == 0 or c0 % 16 == 0)
         if use_h3:
             hsplits = [1] + [k for k in (2, 4, 8, 16) if (c0 + c1) // 16 >= 2 * k and len(splits) > 1]
+            # rounding noise of the fp32 accumulators grows as sqrt(MFMA updates per accumulator) (tools/op_noise.py:
+            # 3.7e-7 at 128 input channels, 7.4e-7 at 512, 1.05e-6 at 1024, halving per 4x reduction split), so an
+            # accumulator never sees more than ACC_CHANNELS input channels: wider layers are reduction-split at least
+            # that many ways (they are the small-grid layers, where the split is what fills the chip anyway)
+            kmin = 1
+            while kmin * ACC_CHANNELS < c0 + c1:
+                kmin *= 2
+            if any(k >= kmin for k in hsplits):
+                hsplits = [k for k in hsplits if k >= kmin]
             cands += [H3_BASE + c + ((k if k > 1 else 0) << 8) for c in range(lib.cm_conv3x3_split_num_configs())
                       for k in hsplits]
         use_smallc = (w_raw is not None and c1 == 0 and c0 * 9 <= 64 and w <= 320 and resid is None
@@ -175,7 +185,7 @@ def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1, w
         # (same cache key with or without the fp32 operand: a caller that dropped it did so because the cached
         #  choice for its calls is a bf16x6 configuration)
         key = (("conv3x3", n, h, w, c0, c1, cout, len(splits), use_split) + (("smallc",) if use_smallc else ())
-               + (("h3",) if use_h3 else ()))
+               + (("h3", ACC_CHANNELS) if use_h3 else ()))
         mfma16 = H3_BASE if use_h3 else SPLIT_BASE
         config = _pick(key, cands, launch, -1 if wp is not None else mfma16)
         if wp is None and config < SPLIT_BASE:      # cached while the fp32 operand still existed: tune the others only
