@@ -112,7 +112,7 @@ def pack_conv3x3(w, c_off=0, cin=None, dgrad=False):
 
 SPLIT_BASE = 1 << 20   # tuned configuration ids >= SPLIT_BASE select the bf16x6 kernel (cm_conv3x3_split)
 H3_BASE = 1 << 21      # ... ids >= H3_BASE the fp16x3 kernel (cm_conv3x3_h3 / cm_wgrad3x3_h3)
-ACC_CHANNELS = int(os.environ.get("CM_ACC_CHANNELS", "128"))   # see conv3x3: longest reduction one accumulator takes
+ACC_CHANNELS = int(os.environ.get("CM_ACC_CHANNELS", "0"))   # see conv3x3: longest reduction one accumulator takes (0: no bound)
 SMALLC_CFG = 1 << 22   # tuned configuration id of the few-input-channels kernels (cm_conv3x3_smallc / cm_wgrad3x3_smallc)
 LAST_CONV_CONFIG = -1   # configuration the most recent conv3x3() call ran with (the engine prunes unused weight packs)
 
@@ -166,11 +166,12 @@ def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1, w
         if use_h3:
             hsplits = [1] + [k for k in (2, 4, 8, 16) if (c0 + c1) // 16 >= 2 * k and len(splits) > 1]
             # rounding noise of the fp32 accumulators grows as sqrt(MFMA updates per accumulator) (tools/op_noise.py:
-            # 3.7e-7 at 128 input channels, 7.4e-7 at 512, 1.05e-6 at 1024, halving per 4x reduction split), so an
-            # accumulator never sees more than ACC_CHANNELS input channels: wider layers are reduction-split at least
-            # that many ways (they are the small-grid layers, where the split is what fills the chip anyway)
+            # 3.7e-7 at 128 input channels, 7.4e-7 at 512, 1.05e-6 at 1024, halving per 4x reduction split).
+            # CM_ACC_CHANNELS=<n> bounds the input channels one accumulator takes by forcing reduction splits on wider
+            # layers; off by default: at model level it bought nothing measurable (tools/noise_probe.py, worst gradient
+            # 1.9e-5 vs 2.0e-5) for 1.3 % of the step.
             kmin = 1
-            while kmin * ACC_CHANNELS < c0 + c1:
+            while ACC_CHANNELS > 0 and kmin * ACC_CHANNELS < c0 + c1:
                 kmin *= 2
             if any(k >= kmin for k in hsplits):
                 hsplits = [k for k in hsplits if k >= kmin]
