@@ -24,7 +24,6 @@ struct FcArgs {
   float* out;
   long long sto;
   int N, H, W, Cin, Cout, R, nbands, nunits;
-  int dbg;   // diagnostic ablation bits (CM_FC_DBG): 1 skip staging, 2 skip MFMA, 4 skip stores
 };
 
 template <int KS2>   // k-steps of two: ceil(Cin * 9 / 2) <= KS2
@@ -61,7 +60,6 @@ __global__ __launch_bounds__(256, 3) void conv3x3_smallc_kernel(FcArgs a) {   //
     const int n = u / a.nbands, y0 = (u % a.nbands) * R;
     const int npx = min(R, H - y0) * W;
     __syncthreads();
-    if (!(a.dbg & 1))
     for (int i = tid; i < xtot; i += 256) {
       const int ci = i / XPL, r = (i % XPL) / PW, cpos = i % PW;
       const int yy = y0 - 1 + r, xx = cpos - 1;
@@ -78,7 +76,6 @@ __global__ __launch_bounds__(256, 3) void conv3x3_smallc_kernel(FcArgs a) {   //
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      if (!(a.dbg & 2))
 #pragma unroll
       for (int s = 0; s < KS2; ++s) {
         const int ke = koff_of(2 * s), ko = koff_of(2 * s + 1);
@@ -86,7 +83,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_smallc_kernel(FcArgs a) {   //
         const float b = Xl[kk >= 0 ? kk + poff : xtot];
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], b, acc, 0, 0, 0);
       }
-      if (live && !(a.dbg & 4)) {
+      if (live) {
         float* op = a.out + (long long)n * a.sto + (long long)y0 * W + p;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -113,8 +110,6 @@ int cm_conv3x3_smallc(const float* x, long long sx, int cin, const float* w, con
   a.R = fc_rows(w_);
   a.nbands = cdiv(h, a.R);
   a.nunits = n * a.nbands;
-  static const int s_dbg = getenv("CM_FC_DBG") ? atoi(getenv("CM_FC_DBG")) : 0;
-  a.dbg = s_dbg;
   const int nblk = a.nunits < 768 ? a.nunits : 768;            // three resident workgroups per CU, several units each
   const size_t lds = ((size_t)cin * (a.R + 2) * (w_ + 2) + FC_MAXPX + 2 * (w_ + 2) + 4) * sizeof(float);
   if (lds > 64 * 1024) return -22;

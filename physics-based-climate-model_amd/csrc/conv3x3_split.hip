@@ -36,7 +36,6 @@ struct SplitArgs {
   float* out;
   long long sto;
   int N, H, W, Cout, CoutP, nsteps, tiles_x, tiles_y;   // nsteps = 16-channel k-steps (= LDS stages)
-  int dbg;     // diagnostic ablation bits (CM_CONVS_DBG): 1 skip global loads, 2 skip MFMA phase, 8 skip convert+store
   int ksplit;  // > 1: blockIdx.z owns a share of the k-steps and accumulates into a pre-zeroed output with atomics
   int prezeroed;   // the caller already zeroed `out` (one fill for several launches): skip the internal zero launch
   const float* winv;      // fp16x3: device scalar, 1 / (power-of-two scale the packed weights carry)
@@ -139,7 +138,6 @@ __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void c
     const int cbase = second ? ch0 - a_C0 : ch0;                 // first channel of the stage inside its tensor
     const int cvalid = (second ? a_C0 + a_C1 : a_C0) - ch0;      // channels of this stage that exist (<= 16 matter)
     cvalid_pending = cvalid;
-    if (a.dbg & 1) return;
     const __amdgpu_buffer_rsrc_t rs = second ? rs1 : rs0;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -161,7 +159,6 @@ __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void c
     for (int i = 0; i < NWR; ++i) wr[i] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wvoff[i], wso, 0);
   };
   auto store_chunk = [&](const float (&xsc_i)[NI]) {
-    if (a.dbg & 8) return;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int e = tid + i * THREADS;
@@ -327,7 +324,6 @@ __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void c
       if (tid < S) smax[pbuf][tid] = 0u;          // read by everyone before this barrier; re-posted two barriers on
     }
     if (chunk + 1 < c_end) load_chunk(chunk + 1);
-    if (!(a.dbg & 2))
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       if constexpr (NP == 3) {
@@ -688,8 +684,6 @@ int cm_conv3x3_split(const float* in0, long long st0, int c0, const float* in1, 
   a.N = n; a.H = h; a.W = w; a.Cout = cout;
   a.CoutP = ((cout + 31) / 32) * 32;
   a.nsteps = (c0 + c1 + SKC - 1) / SKC;
-  static const int s_dbg = getenv("CM_CONVS_DBG") ? atoi(getenv("CM_CONVS_DBG")) : 0;
-  a.dbg = s_dbg;
   a.prezeroed = (config >> 30) & 1;          // bit 30: `out` is already zero (caller batches the fills)
   config &= ~(1 << 30);
   a.ksplit = config >> 8;                    // bits 8.. = K split over blockIdx.z (0/1 = none)
@@ -715,7 +709,6 @@ int cm_conv3x3_h3(const float* in0, long long st0, int c0, const float* in1, lon
   a.N = n; a.H = h; a.W = w; a.Cout = cout;
   a.CoutP = ((cout + 31) / 32) * 32;
   a.nsteps = (c0 + c1 + SKC - 1) / SKC;
-  a.dbg = 0;
   a.prezeroed = (config >> 30) & 1;
   config &= ~(1 << 30);
   a.ksplit = config >> 8;

@@ -27,7 +27,6 @@ struct WgArgs {
   int Ctot, c_off;  // channel count / offset of this conv's input range inside the full weight
   int N, H, W, Cout;
   int tiles_x, tiles_y, units, units_per_block;
-  int dbg;  // diagnostic ablation bits (CM_WGRAD_DBG): 1 skip global loads, 2 skip MFMA phase, 4 skip atomics
 };
 
 // Wave roles: wave = (group, kernel row dy); group = (mo, ks): mo selects the 32-cout sub-block, ks the share of the
@@ -150,8 +149,7 @@ __global__ __launch_bounds__(192 * MO * KS, 2) void wgrad3x3_mfma_kernel(WgArgs 
     }
   };
 
-  const int dbg = a.dbg;
-  if (u_begin < u_end && !(dbg & 1)) load_unit(u_begin);
+  if (u_begin < u_end) load_unit(u_begin);
   for (int u = u_begin; u < u_end; ++u) {
     __syncthreads();  // previous unit's MFMA phase has finished reading LDS
     int ts = tid;
@@ -181,9 +179,8 @@ __global__ __launch_bounds__(192 * MO * KS, 2) void wgrad3x3_mfma_kernel(WgArgs 
       }
     }
     __syncthreads();
-    if (u + 1 < u_end && !(dbg & 1)) load_unit(u + 1);
+    if (u + 1 < u_end) load_unit(u + 1);
     __builtin_amdgcn_sched_barrier(0);
-    if (dbg & 2) continue;
 
     // MFMA phase: a runtime loop over row groups (RSTEP tile rows each; 2 for odd TW so that pixel pairs tile the
     // group exactly), the pairs inside a group unrolled with compile-time LDS offsets.  The KS wave groups take
@@ -213,7 +210,7 @@ __global__ __launch_bounds__(192 * MO * KS, 2) void wgrad3x3_mfma_kernel(WgArgs 
 
   // ---- accumulate: D[i = cout][j = channel]; lane holds channel ci0 + l31 ----
   const int ch = ci0 + l31;
-  if (ch < Cin && u_begin < u_end && !(dbg & 4)) {
+  if (ch < Cin && u_begin < u_end) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + mo * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -612,8 +609,6 @@ int cm_wgrad3x3(const float* x0, long long sx0, int c0, const float* x1, long lo
   a.N = n; a.H = h; a.W = w; a.Cout = cout;
   a.tiles_x = a.tiles_y = a.units = 0;
   a.units_per_block = 0;
-  static const int s_dbg = getenv("CM_WGRAD_DBG") ? atoi(getenv("CM_WGRAD_DBG")) : 0;
-  a.dbg = s_dbg;
 
   if (config < 0) config = cm_wgrad3x3_pick_config(n, h, w, cout);
   if ((config >> 8) > 0) a.units_per_block = config >> 8;   // bits 8.. = grid size in quarter rounds of resident slots

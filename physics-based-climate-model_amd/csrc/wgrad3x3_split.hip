@@ -34,7 +34,6 @@ struct WsArgs {
   int Ctot, c_off;  // channel count / offset of this conv's input range inside the full weight
   int N, H, W, Cout;
   int RB, ngroups, nsegs, nunits;   // rows per band; units = groups x segments x bands
-  int dbg;  // diagnostic ablation bits (CM_WGS_DBG): 1 skip global loads, 2 skip MFMA phase, 4 skip atomics, 8 skip convert+store
 };
 
 constexpr int cdiv_c(int a, int b) { return (a + b - 1) / b; }
@@ -179,7 +178,7 @@ __global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 3 : 1) void wgrad3x3_sp
       if (xs + t <= xe) xrow = xs + t;
       const int d = xs + t - 1;
       if (d >= y0 && d < y1) drow = d;
-      if (!(a.dbg & 1)) {
+      {
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
           const int row = it_x[k] ? xrow : drow;
@@ -229,7 +228,7 @@ __global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 3 : 1) void wgrad3x3_sp
     // The fp32 -> 3 x bf16 conversion of the rows just requested runs in the shadow of the second half of the steps
     // (a few VALU instructions per MFMA group), so that after the barrier only the LDS writes remain.
     bool converted = false;
-    if (crow >= 0 && !(a.dbg & 2)) {
+    if (crow >= 0) {
       const int yy = crow + dy;
       if (yy >= 0 && yy < H) {
         constexpr int JN = cdiv_c(NPAIR, KS);
@@ -306,7 +305,7 @@ __global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 3 : 1) void wgrad3x3_sp
   #pragma unroll
               for (int m = 0; m < MO; ++m) acc[m][d] = mma(af[jj & 1][m], bf[s & 1], acc[m][d]);
             }
-            if (SHADOW && s >= S0 && !(a.dbg & 8)) {
+            if (SHADOW && s >= S0) {
   #pragma unroll
               for (int c = (s - S0) * UPS; c < (s - S0 + 1) * UPS && c < NUNIT; ++c) convert_unit(c);
             }
@@ -317,7 +316,7 @@ __global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 3 : 1) void wgrad3x3_sp
       }
     }
     if (!have) break;
-    if (SHADOW && !converted && !(a.dbg & 8)) {
+    if (SHADOW && !converted) {
 #pragma unroll
       for (int c = 0; c < NUNIT; ++c) convert_unit(c);
     }
@@ -358,7 +357,7 @@ __global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 3 : 1) void wgrad3x3_sp
       if (xrow >= 0) slot_sh[(xrow + 1) % 3] = shx;
       d_sh = shy;
     }
-    if (!(a.dbg & 8)) {
+    {
 #pragma unroll
       for (int k = 0; k < NIT; ++k) {
         if (!SHADOW) {
@@ -434,7 +433,7 @@ __global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 3 : 1) void wgrad3x3_sp
   }
   // D[i][j]: lane holds column j = l31 (input channel), rows (r&3) + 8*(r>>2) + 4*half (output channel)
   const int ci = ci0 + l31;
-  if (ci >= a.C0 + a.C1 || (a.dbg & 4)) return;
+  if (ci >= a.C0 + a.C1) return;
 #pragma unroll
   for (int m = 0; m < MO; ++m)
 #pragma unroll
@@ -529,8 +528,6 @@ int cm_wgrad3x3_split(const float* x0, long long sx0, int c0, const float* x1, l
   a.dy = dy; a.sdy = sdy; a.g = g; a.Ctot = ctot; a.c_off = c_off;
   a.N = n; a.H = h; a.W = w; a.Cout = cout;
   a.RB = a.ngroups = a.nsegs = a.nunits = 0;
-  static const int s_dbg = getenv("CM_WGS_DBG") ? atoi(getenv("CM_WGS_DBG")) : 0;
-  a.dbg = s_dbg;
   const int rounds4 = (config >> 8) > 0 ? (config >> 8) : 4;   // bits 8.. = grid size in quarter rounds of resident slots
   config &= 0xff;
   return c1 > 0 ? dispatch_ws<true, 3>(config, a, rounds4, (hipStream_t)stream)
@@ -550,7 +547,6 @@ int cm_wgrad3x3_h3(const float* x0, long long sx0, int c0, const float* x1, long
   a.dy = dy; a.sdy = sdy; a.g = g; a.Ctot = ctot; a.c_off = c_off;
   a.N = n; a.H = h; a.W = w; a.Cout = cout;
   a.RB = a.ngroups = a.nsegs = a.nunits = 0;
-  a.dbg = 0;
   const int rounds4 = (config >> 8) > 0 ? (config >> 8) : 4;
   config &= 0xff;
   return c1 > 0 ? dispatch_ws<true, 2>(config, a, rounds4, (hipStream_t)stream)
