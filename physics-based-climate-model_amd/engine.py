@@ -358,19 +358,16 @@ class _SideStream:
         self.keep.clear()
 
 
-# Both side-stream overlaps are OFF by default.  Round-1 findings on MI355X (config 2):
-#  * performance: with the fp32 weight-gradient kernel (12 waves, ~100 KB LDS per workgroup) overlapping all weight
-#    gradients with the data-gradient chain was 5 % slower (the kernels time-slice the CUs); with the bf16x6 kernels
-#    (3-/6-wave workgroups, <= 77 KB) it measured 0-4 % faster depending on the box;
-#  * correctness: in EAGER mode with bf16x6 weight-gradient workgroups co-resident on the CUs, the main chain produced
-#    non-finite values from the second step on.  Traced (tools/dbg_overlap.py) to ONE lost amax tie count: the gate
-#    backward read the SE scale `s` (two uniform-address 16-byte loads per eight channels) and got the PREVIOUS step's
-#    values (same address, equal up to rounding), so no channel matched the stored maximum, cnt = 0, division by zero
-#    downstream.  Rewriting that read as per-lane dword loads removed the failure (7 of 7 runs, eager soak included),
-#    but the mechanism is not understood (stale vector-L1 lines while two queues share a CU?), and every kernel here
-#    reads small device-written tensors (statistics, scales, Adam-updated parameters) through uniform loads.  Until
-#    that is understood the serial schedule is the only supported one; CM_OVERLAP_WGRAD=1 / CM_OVERLAP_LSTM=1 are for
-#    investigation.
+# Both side-stream overlaps are OFF by default (0-4 % either way on config 2, box dependent; with the fp32 weight-gradient
+# kernel 5 % slower).  Round 1 saw non-finite values in EAGER mode with CM_OVERLAP_WGRAD=1: the gate backward compared
+# a2*s with the channel maximum the forward had STORED, once received a stale SE scale `s`, found no channel equal to
+# the stored maximum, and divided by a tie count of 0.  Round 2: both load forms compile to
+# vector-memory loads through the same L1 (no scalar cache involved); tools/overlap_probe.py re-runs the suspected
+# uniform 16-byte form under the overlapped eager schedule and compares every launch's maxima with a serial
+# recomputation -- 0 mismatches in 56 launches, the failure does not reproduce on the current stack; and the gate
+# backward no longer depends on bitwise agreement with another launch: it derives maximum AND tie count from the values
+# it reads itself (count >= 1 by construction).  tests/test_model_gpu.py::test_side_stream_overlap_eager_three_steps runs three
+# eager steps of the overlapped schedule against the serial one.
 OVERLAP_WGRAD = os.environ.get("CM_OVERLAP_WGRAD", "0") != "0"
 
 # The ConvLSTM recurrence is a serial chain of small launches (N = B samples at 6x9: <= 256 workgroups each) that leaves
