@@ -71,9 +71,13 @@ int cm_conv3x3_split(const float* in0, long long st0, int c0, const float* in1, 
  * cm_conv3x3_h3_packed_bytes() bytes; scratch = ndesc + total_blocks floats; scratch[job] is that job's wscale_inv.   */
 long long cm_conv3x3_h3_packed_bytes(int k_channels, int out_channels);
 int cm_pack_conv3x3_h3_batch(const void* descs_dev, int ndesc, int total_blocks, float* scratch, cm_stream stream);
+/* sample_be (optional; [n] entries be_stride apart, zeroed by the caller): entry i is raised (atomic max) to the biased
+ * exponent (float bits >> 23) of max |input of sample i| over both input tensors -- the per-sample magnitudes
+ * cm_wgrad3x3_h3 needs, produced for free by the launch that reads the same tensor. */
 int cm_conv3x3_h3(const float* in0, long long st0, int c0, const float* in1, long long st1, int c1, const void* wps,
                   const float* wscale_inv, const float* bias, const float* resid, long long st_resid, float* out,
-                  long long st_out, int n, int h, int w, int cout, int config, cm_stream stream);
+                  long long st_out, unsigned* sample_be, long long be_stride, int n, int h, int w, int cout, int config,
+                  cm_stream stream);
 
 /* Forward conv for VERY FEW input channels (cin * 9 <= 64; the first layer, src/unet.py:36 at
  * src/unet_convlstm_attention.py:35): the reduction index is the (input channel, tap) pair, fp32 MFMA, weights read
@@ -100,10 +104,18 @@ int cm_wgrad3x3_split_num_configs(void);
 int cm_wgrad3x3_split(const float* x0, long long sx0, int c0, const float* x1, long long sx1, int c1, const float* dy,
                       long long sdy, float* g, int ctot, int c_off, int n, int h, int w, int cout, int config,
                       cm_stream stream);
-/* fp16x3 form of cm_wgrad3x3_split: same arguments and configurations, half the matrix work (cm_conv3x3_h3). */
+/* fp16x3 form of cm_wgrad3x3_split: same configurations, half the matrix work.  The reduction mixes samples, so the
+ * power-of-two scaling is per sample and product balanced (csrc/wgrad3x3_split.hip): be_x / be_y [n] = biased exponent of
+ * max |x| / max |dy| of every sample (0: all zeros), from cm_conv3x3_h3's sample_be or cm_sample_exponents; values above
+ * the true exponent are safe (they only cost precision).  A left-padded window (main_final.py:127-131) next to real
+ * ones keeps its accuracy this way. */
 int cm_wgrad3x3_h3(const float* x0, long long sx0, int c0, const float* x1, long long sx1, int c1, const float* dy,
-                   long long sdy, float* g, int ctot, int c_off, int n, int h, int w, int cout, int config,
-                   cm_stream stream);
+                   long long sdy, const unsigned* be_x, const unsigned* be_y, float* g, int ctot, int c_off, int n,
+                   int h, int w, int cout, int config, cm_stream stream);
+/* be[i * be_stride] = max(be[i * be_stride], biased exponent of max |x[i * stride .. + len)|), i < n; be zeroed by the
+ * caller.  For callers whose x / dy were not read by a cm_conv3x3_h3 launch. */
+int cm_sample_exponents(const float* x, long long stride, int n, long long len, unsigned* be, long long be_stride,
+                        cm_stream stream);
 /* Weight gradient for VERY FEW input channels (cin * 9 <= 64, the first layer: src/unet.py:36 at
  * src/unet_convlstm_attention.py:35): GEMM columns are the (input channel, tap) pairs, fp32 MFMA, same staging
  * format G[cout][9][ctot].  w % 4 == 0, w <= 320, st_dy % 4 == 0.  scratch: cm_wgrad3x3_smallc_scratch_elems()

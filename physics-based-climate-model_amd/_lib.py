@@ -30,6 +30,8 @@ _CTYPES = {
     "const int*": ctypes.c_void_p,
     "int*": ctypes.c_void_p,
     "const long long*": ctypes.c_void_p,
+    "unsigned*": ctypes.c_void_p,
+    "const unsigned*": ctypes.c_void_p,
     "double": ctypes.c_double,
     "double*": ctypes.c_void_p,
     "const double*": ctypes.c_void_p,

@@ -39,6 +39,8 @@ struct SplitArgs {
   int ksplit;  // > 1: blockIdx.z owns a share of the k-steps and accumulates into a pre-zeroed output with atomics
   int prezeroed;   // the caller already zeroed `out` (one fill for several launches): skip the internal zero launch
   const float* winv;      // fp16x3: device scalar, 1 / (power-of-two scale the packed weights carry)
+  unsigned* be_out;       // fp16x3, optional: per-sample biased exponent of max|input| (atomic max), see cm_conv3x3_h3
+  long long be_stride;
 };
 
 // Workgroups with one 32x32 tile per wave sit 2 registers above the 3-waves-per-SIMD allocation (170 of 168): ask for
@@ -380,6 +382,15 @@ __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void c
 
   // ---- epilogue (same accumulator map as the fp32 kernel) ----
   if constexpr (NP == 2) {
+    // publish what this workgroup knows about its samples' magnitudes (the fp16x3 weight gradient scales per sample)
+    if (a.be_out != nullptr && tid < S && n0 + tid < a.N) {
+      unsigned be = be_run[0];
+#pragma unroll
+      for (int s_ = 1; s_ < S; ++s_) be = tid == s_ ? be_run[s_] : be;
+      if (be) atomicMax(a.be_out + (long long)(n0 + tid) * a.be_stride, be);
+    }
+  }
+  if constexpr (NP == 2) {
     // undo the operand scales: 2^(be - 140) for the input (0 if nothing but zeros was staged), *winv for the weights
     const float winv = a.winv[0];
 #pragma unroll
@@ -691,15 +702,20 @@ int cm_conv3x3_split(const float* in0, long long st0, int c0, const float* in1, 
   if (a.ksplit > 1 && resid == out) return -22;   // the in-place residual would be zeroed
   a.tiles_x = a.tiles_y = 0;
   a.winv = nullptr;
+  a.be_out = nullptr; a.be_stride = 0;
   if (!offsets_fit_32bit(a)) return -22;
   return c1 > 0 ? dispatch_s<true, 3>(config, a, (hipStream_t)stream) : dispatch_s<false, 3>(config, a, (hipStream_t)stream);
 }
 
 /* cm_conv3x3_split on two fp16 pieces per operand and three products ("fp16x3", csrc/split_f16.h): same contract and
- * config encoding; wps / wscale_inv from cm_pack_conv3x3_h3_batch.  Input scaling is internal (running maximum). */
+ * config encoding; wps / wscale_inv from cm_pack_conv3x3_h3_batch.  Input scaling is internal (running maximum).
+ * sample_be (optional, [n] entries be_stride apart, zeroed by the caller): the kernel raises entry i to the biased exponent
+ * of max |input of sample i| over both input tensors (atomic max over workgroups) -- the per-sample magnitudes the
+ * fp16x3 weight gradient (cm_wgrad3x3_h3) needs, obtained for free from the launch that reads the same tensor. */
 int cm_conv3x3_h3(const float* in0, long long st0, int c0, const float* in1, long long st1, int c1, const void* wps,
                   const float* wscale_inv, const float* bias, const float* resid, long long st_resid, float* out,
-                  long long st_out, int n, int h, int w, int cout, int config, cm_stream stream) {
+                  long long st_out, unsigned* sample_be, long long be_stride, int n, int h, int w, int cout, int config,
+                  cm_stream stream) {
   if (n <= 0 || h <= 0 || w <= 0 || cout <= 0 || c0 <= 0 || c1 < 0 || config < 0 || !wscale_inv) return -22;
   if (c1 > 0 && (c0 % SKC) != 0) return -22;
   if (resid && st_resid != st_out) return -22;
@@ -716,6 +732,7 @@ int cm_conv3x3_h3(const float* in0, long long st0, int c0, const float* in1, lon
   if (a.ksplit > 1 && resid == out) return -22;
   a.tiles_x = a.tiles_y = 0;
   a.winv = wscale_inv;
+  a.be_out = sample_be; a.be_stride = be_stride;
   if (!offsets_fit_32bit(a)) return -22;
   return c1 > 0 ? dispatch_s<true, 2>(config, a, (hipStream_t)stream) : dispatch_s<false, 2>(config, a, (hipStream_t)stream);
 }

@@ -34,6 +34,8 @@ struct WsArgs {
   int Ctot, c_off;  // channel count / offset of this conv's input range inside the full weight
   int N, H, W, Cout;
   int RB, ngroups, nsegs, nunits;   // rows per band; units = groups x segments x bands
+  const unsigned* bex;              // fp16x3: biased exponent of max|x| per sample [N] (0: the sample is all zeros)
+  const unsigned* bey;              // ... of max|dy| per sample
 };
 
 constexpr int cdiv_c(int a, int b) { return (a + b - 1) / b; }
@@ -56,11 +58,17 @@ struct WsGeom {
 // __launch_bounds__ argument is hip-clang's MIN WAVES PER EU).
 constexpr bool ws_lean(int mo, int ks) { return mo == 1 && ks == 2; }
 
-// NP = 3: bf16x6; NP = 2: fp16x3 (split_f16.h).  fp16x3 scaling: one power of two per staged X row and per staged dY row,
-// from the RUNNING maxima of everything this workgroup has staged of each operand (exact, no history; the reduction
-// mixes samples, so its error is relative to the largest contributions, which is what a sum needs).  Every ring slot
-// remembers the shift it was converted with; a wave's accumulators carry the shift sum of the rows they last
-// accumulated, and follow when it shrinks (the sequence a wave sees is monotone).
+// NP = 3: bf16x6; NP = 2: fp16x3 (split_f16.h).  fp16x3 scaling is PER SAMPLE and product balanced.  The reduction runs
+// over (sample, pixel) and an LDS record holds 8 samples of one pixel, so samples of very different magnitude meet in
+// one accumulator: a left-padded all-zero frame (GroupNorm's rstd = 316 per layer puts its dY 2^28 above a real
+// frame's, while its own contribution cancels) next to real frames.  One scale per record group would flush the real
+// frames' dY to zero.  Instead every sample n gets its own pair of exact powers of two (a_n for x, b_n for dy) with
+// a_n * b_n = P THE SAME FOR ALL SAMPLES, so the accumulators carry one constant scale and no rescaling ever happens:
+// with ex_n, ey_n the exponents of the sample's max|x|, max|dy| (published by the forward / data-gradient conv that
+// read the same tensors, or by cm_sample_exponents) and E = max_n(ex_n + ey_n), the deficit d_n = E - ex_n - ey_n of a
+// sample's largest product is split between its operands: a_n = 2^(140 - ex_n - floor(d_n/2)), b_n = 2^(140 - ey_n -
+// ceil(d_n/2)).  Every scaled value stays below 2^14, P = 2^(280 - E), and a sample keeps its 22 bits as long as
+// d_n < ~34 (beyond that its products are below fp32 resolution of the sum anyway).
 template <int TW, int MO, int KS, bool DUAL, int NP>
 __global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 3 : 1) void wgrad3x3_split_kernel(WsArgs a) {
   using G = WsGeom<TW, MO, KS, NP>;
@@ -101,7 +109,7 @@ __global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 3 : 1) void wgrad3x3_sp
   constexpr int NUNIT = 16 * NIT;                // conversion units (one split3_pair each) per thread and iteration
   // converting in the MFMA shadow keeps 48 result registers per item alive across the barrier: only where they fit
   constexpr bool LEAN = ws_lean(MO, KS);
-  constexpr bool SHADOW = NP == 3 && NIT == 1 && MO == 1 && THREADS <= 384 && !LEAN;   // (fp16x3: the scale is only known after the barrier)
+  constexpr bool SHADOW = NIT == 1 && MO == 1 && THREADS <= 384 && !LEAN;
   bool it_x[NIT];
   int it_ch[NIT], it_c0[NIT], it_rec[NIT];       // channel inside the tile, first column, first LDS record
 #pragma unroll
@@ -131,6 +139,17 @@ __global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 3 : 1) void wgrad3x3_sp
   int n0 = 0, x0 = 0, y0 = 0, y1 = 0, xs = 0, xe = 0, nval = 0;
   int it_off[NIT];        // element offset of the quad inside (sample, row 0); may be -1 at the left image edge
   unsigned it_msk[NIT];   // bit e: element e of the quad is a real pixel of a real channel
+  // fp16x3: E = max over ALL samples of (ex + ey) (wave uniform), then the unit's eight scale pairs
+  int emax = 0;
+  float sxs[8], sys[8];
+  if constexpr (NP == 2) {
+    float m = 0.f;
+    for (int n = lane; n < N; n += 64) {
+      const unsigned ex = a.bex[n], ey = a.bey[n];
+      m = fmaxf(m, (ex && ey) ? (float)(ex + ey) : 0.f);
+    }
+    emax = (int)wave_max_nonneg(m);
+  }
   auto decode = [&]() {
     const int g = u % a.ngroups, rest = u / a.ngroups;
     const int seg = rest % a.nsegs, band = rest / a.nsegs;
@@ -152,6 +171,18 @@ __global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 3 : 1) void wgrad3x3_sp
       it_msk[k] = m;
       it_off[k] = ((it_x[k] ? cbase : co0) + max(it_ch[k], 0)) * HW + xq;
     }
+    if constexpr (NP == 2) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int n = __builtin_amdgcn_readfirstlane(n0 + min(j, nval - 1));
+        const int ex = (int)a.bex[n], ey = (int)a.bey[n];
+        const int d = emax - (ex + ey);
+        const int fx = 267 - ex - (d >> 1), fy = 267 - ey - ((d + 1) >> 1);
+        const bool ok = ex > 0 && ey > 0 && j < nval && fx >= 1 && fx <= 254 && fy >= 1 && fy <= 254;
+        sxs[j] = ok ? __uint_as_float((unsigned)fx << 23) : 0.f;
+        sys[j] = ok ? __uint_as_float((unsigned)fy << 23) : 0.f;
+      }
+    }
   };
   if (have) decode();
   int t = 0;
@@ -159,16 +190,6 @@ __global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 3 : 1) void wgrad3x3_sp
 
   f32x4 lr[NIT][8];        // prefetched quads: [item][sample]
   u32x4 cv[NIT][3][4];     // converted records: [item][piece][element]
-  // fp16x3 scaling state (all wave uniform).  shift = 140 - max(biased exponent of the running maximum, 13).
-  __shared__ unsigned smaxw[2][2];          // [iteration parity][X, dY] posted maxima (float bits, LDS atomic max)
-  unsigned bex_run = 0, bey_run = 0;
-  int slot_sh[3] = {127, 127, 127};         // shift each X ring slot was converted with
-  int d_sh = 127, d_sh_mma = 127;           // ... the dY row being staged / the one the MFMA phase reads
-  int acc_sx = 127, acc_sy = 127;           // shifts the accumulators currently carry (acc = true * 2^(sx + sy))
-  bool acc_any = false;
-  float xsc = 1.f, ysc = 1.f;
-  if (NP == 2 && tid < 4) smaxw[tid >> 1][tid & 1] = 0u;
-  int iter = 0;
   __syncthreads();
 
   while (true) {
@@ -215,8 +236,8 @@ __global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 3 : 1) void wgrad3x3_sp
       if constexpr (NP == 3) {
         split3_pair(ok0 ? lr[k][2 * q][e] : 0.f, ok1 ? lr[k][2 * q + 1][e] : 0.f, a_, b_, c_);
       } else {
-        const float sc = it_x[k] ? xsc : ysc;
-        split2_pair_f16(ok0 ? lr[k][2 * q][e] * sc : 0.f, ok1 ? lr[k][2 * q + 1][e] * sc : 0.f, a_, b_);
+        const float s0 = it_x[k] ? sxs[2 * q] : sys[2 * q], s1 = it_x[k] ? sxs[2 * q + 1] : sys[2 * q + 1];
+        split2_pair_f16(ok0 ? lr[k][2 * q][e] * s0 : 0.f, ok1 ? lr[k][2 * q + 1][e] * s1 : 0.f, a_, b_);
       }
       cv[k][0][e][q] = a_;
       cv[k][1][e][q] = b_;
@@ -234,20 +255,6 @@ __global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 3 : 1) void wgrad3x3_sp
         constexpr int JN = cdiv_c(NPAIR, KS);
         constexpr int NSTEP = JN * 3, S0 = NSTEP / 2, UPS = cdiv_c(NUNIT, NSTEP - S0);   // units per late step
         const int jb = ks * JN;
-        if constexpr (NP == 2) {          // bring the accumulators to the shift sum of the rows about to be accumulated
-          const int sx = slot_sh[(yy + 1) % 3], sy = d_sh_mma;
-          if (acc_any && sx + sy != acc_sx + acc_sy) {
-            const int d = (acc_sx + acc_sy) - (sx + sy);                    // >= 0: shifts only shrink
-            const float f = d > 126 ? 0.f : __uint_as_float((unsigned)(127 - d) << 23);
-#pragma unroll
-            for (int m = 0; m < MO; ++m)
-#pragma unroll
-              for (int dd = 0; dd < 3; ++dd)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][dd][r] *= f;
-          }
-          acc_sx = sx; acc_sy = sy; acc_any = true;
-        }
         const u32x4* xb = Xl + ((yy + 1) % 3) * XSLOT + l31 * XP + half + 1;
         const u32x4* db = Dl + l31 * DP + half;
         u32x4 af[2][MO][NP], bf[2][NP];
@@ -321,42 +328,8 @@ __global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 3 : 1) void wgrad3x3_sp
       for (int c = 0; c < NUNIT; ++c) convert_unit(c);
     }
 
-    // ---- fp16x3: post this iteration's maxima (the loads must have landed), combine them after the barrier ----
-    const int par = iter & 1;
-    if constexpr (NP == 2) {
-      float mx = 0.f, my = 0.f;
-#pragma unroll
-      for (int k = 0; k < NIT; ++k) {
-        const int row = it_x[k] ? xrow : drow;
-        if (row < 0) continue;
-        float m = 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const bool live = (it_msk[k] >> e) & 1;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) m = fmaxf(m, (live && j < nval) ? fabsf(lr[k][j][e]) : 0.f);
-        }
-        mx = fmaxf(mx, it_x[k] ? m : 0.f);
-        my = fmaxf(my, it_x[k] ? 0.f : m);
-      }
-      mx = wave_max_nonneg(mx);
-      my = wave_max_nonneg(my);
-      if (lane == 0) {
-        atomicMax(&smaxw[par][0], __float_as_uint(mx));
-        atomicMax(&smaxw[par][1], __float_as_uint(my));
-      }
-    }
     // ---- store the converted rows ----
     __syncthreads();
-    if constexpr (NP == 2) {
-      bex_run = max(bex_run, (smaxw[par][0] >> 23) & 0xffu);
-      bey_run = max(bey_run, (smaxw[par][1] >> 23) & 0xffu);
-      const int shx = 140 - (int)max(bex_run, 13u), shy = 140 - (int)max(bey_run, 13u);
-      xsc = __uint_as_float((unsigned)(shx + 127) << 23);
-      ysc = __uint_as_float((unsigned)(shy + 127) << 23);
-      if (xrow >= 0) slot_sh[(xrow + 1) % 3] = shx;
-      d_sh = shy;
-    }
     {
 #pragma unroll
       for (int k = 0; k < NIT; ++k) {
@@ -379,11 +352,6 @@ __global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 3 : 1) void wgrad3x3_sp
       }
     }
     __syncthreads();
-    if constexpr (NP == 2) {
-      if (tid < 2) smaxw[par][tid] = 0u;     // everyone has read it; it is posted to again two iterations from now
-      d_sh_mma = d_sh;
-      ++iter;
-    }
     crow = drow;
     // ---- advance (unit, t) ----
     ++t;
@@ -395,9 +363,10 @@ __global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 3 : 1) void wgrad3x3_sp
     }
   }
 
-  if constexpr (NP == 2) {                 // undo the operand shifts (two exact steps: their sum may exceed fp32's range)
-    const float fx = acc_any ? __uint_as_float((unsigned)(127 - acc_sx) << 23) : 0.f;
-    const float fy = acc_any ? __uint_as_float((unsigned)(127 - acc_sy) << 23) : 0.f;
+  if constexpr (NP == 2) {                 // undo P = 2^(280 - E) (two exact steps: the exponent may exceed fp32's range)
+    const int e = emax - 280, e1 = e >> 1, e2 = e - e1;
+    const float fx = emax > 0 ? __uint_as_float((unsigned)min(max(127 + e1, 1), 254) << 23) : 0.f;
+    const float fy = emax > 0 ? __uint_as_float((unsigned)min(max(127 + e2, 1), 254) << 23) : 0.f;
 #pragma unroll
     for (int m = 0; m < MO; ++m)
 #pragma unroll
@@ -451,6 +420,21 @@ __global__ __launch_bounds__(192 * KS, ws_lean(MO, KS) ? 3 : 1) void wgrad3x3_sp
 // ring -- was built and measured in round 1: correct, but 15-20 % SLOWER (256->256 @6x9: 112 vs 93 us).  Its ablation
 // showed why: the staging side alone takes 105 us on two waves; the fp32 -> 3 x bf16 conversion is VALU work of the
 // same order as the MFMA time and needs all four SIMDs, so concentrating it on dedicated waves starves it.)
+
+__global__ __launch_bounds__(256) void sample_exponents_kernel(const float* __restrict__ x, long long stride,
+                                                                long long len, unsigned* __restrict__ be,
+                                                                long long be_stride) {
+  const float* xs = x + (long long)blockIdx.y * stride;
+  float m = 0.f;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < len; i += 256LL * gridDim.x) {
+    const float v = fabsf(xs[i]);
+    m = (v > m || v != v) ? v : m;          // (a NaN sticks)
+  }
+  unsigned bits = __float_as_uint(m) >> 23 & 0xffu;
+  // wave reduction on the exponent (an integer in [0, 255], exact as a float)
+  const unsigned wm = (unsigned)wave_max_nonneg((float)bits);
+  if ((threadIdx.x & 63) == 0 && wm) atomicMax(be + (long long)blockIdx.y * be_stride, wm);
+}
 
 struct WsCfg {
   int tw, mo, ks;
@@ -528,18 +512,22 @@ int cm_wgrad3x3_split(const float* x0, long long sx0, int c0, const float* x1, l
   a.dy = dy; a.sdy = sdy; a.g = g; a.Ctot = ctot; a.c_off = c_off;
   a.N = n; a.H = h; a.W = w; a.Cout = cout;
   a.RB = a.ngroups = a.nsegs = a.nunits = 0;
+  a.bex = a.bey = nullptr;
   const int rounds4 = (config >> 8) > 0 ? (config >> 8) : 4;   // bits 8.. = grid size in quarter rounds of resident slots
   config &= 0xff;
   return c1 > 0 ? dispatch_ws<true, 3>(config, a, rounds4, (hipStream_t)stream)
                 : dispatch_ws<false, 3>(config, a, rounds4, (hipStream_t)stream);
 }
 
-/* fp16x3 form of cm_wgrad3x3_split (same arguments, configurations and staging format; see cm_conv3x3_h3 and
- * csrc/split_f16.h): two fp16 pieces per operand, three products, in-kernel power-of-two scaling. */
+/* fp16x3 form of cm_wgrad3x3_split (same configurations and staging format; csrc/split_f16.h): two fp16 pieces per
+ * operand, three products.  be_x / be_y [n]: biased exponent (float bits >> 23) of max|x| / max|dy| of every sample, 0
+ * for an all-zero sample -- as published by cm_conv3x3_h3 (sample_be) for the tensors it read, or by
+ * cm_sample_exponents.  They need not be tight: any value >= the true exponent is safe (it only costs precision). */
 int cm_wgrad3x3_h3(const float* x0, long long sx0, int c0, const float* x1, long long sx1, int c1, const float* dy,
-                   long long sdy, float* g, int ctot, int c_off, int n, int h, int w, int cout, int config,
-                   cm_stream stream) {
-  if (n <= 0 || h <= 0 || w <= 0 || cout <= 0 || c0 <= 0 || c1 < 0 || c_off < 0 || c_off + c0 + c1 > ctot || config < 0)
+                   long long sdy, const unsigned* be_x, const unsigned* be_y, float* g, int ctot, int c_off, int n,
+                   int h, int w, int cout, int config, cm_stream stream) {
+  if (n <= 0 || h <= 0 || w <= 0 || cout <= 0 || c0 <= 0 || c1 < 0 || c_off < 0 || c_off + c0 + c1 > ctot ||
+      config < 0 || !be_x || !be_y)
     return -22;
   if (c1 > 0 && (c0 % 32) != 0) return -22;
   WsArgs a;
@@ -547,10 +535,23 @@ int cm_wgrad3x3_h3(const float* x0, long long sx0, int c0, const float* x1, long
   a.dy = dy; a.sdy = sdy; a.g = g; a.Ctot = ctot; a.c_off = c_off;
   a.N = n; a.H = h; a.W = w; a.Cout = cout;
   a.RB = a.ngroups = a.nsegs = a.nunits = 0;
+  a.bex = be_x; a.bey = be_y;
   const int rounds4 = (config >> 8) > 0 ? (config >> 8) : 4;
   config &= 0xff;
   return c1 > 0 ? dispatch_ws<true, 2>(config, a, rounds4, (hipStream_t)stream)
                 : dispatch_ws<false, 2>(config, a, rounds4, (hipStream_t)stream);
+}
+
+/* be[i * be_stride] = max(be[...], biased exponent of max |x[i * stride + 0 .. len)|) for i < n (0 stays 0 for an
+ * all-zero sample; NaN / inf give 255).  `be` must have been zeroed (or hold a previous partial result). */
+int cm_sample_exponents(const float* x, long long stride, int n, long long len, unsigned* be, long long be_stride,
+                        cm_stream stream) {
+  if (n <= 0 || len <= 0 || !x || !be) return -22;
+  const int per = (int)((len + 256LL * 16 - 1) / (256LL * 16));
+  const int blocks = per < 64 ? (per < 1 ? 1 : per) : 64;
+  sample_exponents_kernel<<<dim3(blocks, n), 256, 0, (hipStream_t)stream>>>(x, stride, len, be, be_stride);
+  CM_CHECK_LAUNCH();
+  return 0;
 }
 
 }  // extern "C"

@@ -25,7 +25,7 @@ Params = Dict[str, Tensor]
 
 class _BlockCtx:
     """Tensors one ConvBlock keeps for its backward."""
-    __slots__ = ("x0", "x1", "y1", "a1", "st1", "y2", "a2", "st2", "pooled", "z", "s", "fmap", "gate", "out")
+    __slots__ = ("x0", "x1", "y1", "a1", "st1", "y2", "a2", "st2", "pooled", "z", "s", "fmap", "gate", "out", "be")
 
 
 def _conv_jobs(p: Params, need_input_grad: bool):
@@ -261,11 +261,30 @@ def pack_weights(p: Params, need_input_grad: bool = False) -> Dict[str, Tensor]:
 
 
 # ------------------------------------------------------------------------------------------------- ConvBlock
-def _block_fwd(p: Params, pk, prefix: str, x0: Tensor, x1: Optional[Tensor], save: bool, pool: bool = False):
+class _BeArena:
+    """Per-forward pool of per-sample exponent tables (ops.SampleExponents): the fp16x3 convs publish the magnitudes of
+    the tensors they read, the fp16x3 weight gradients of the same tensors consume them.  One zero fill per step."""
+
+    def __init__(self, device, capacity: int):
+        self.buf = _zeros(capacity, device=device).view(torch.int32)
+        self.used = 0
+
+    def take(self, n: int) -> "ops.SampleExponents":
+        if self.used + n > self.buf.numel():
+            raise RuntimeError("exponent-table arena too small")
+        t = self.buf[self.used:self.used + n]
+        self.used += n
+        return ops.SampleExponents(t)
+
+
+def _block_fwd(p: Params, pk, prefix: str, x0: Tensor, x1: Optional[Tensor], save: bool, pool: bool = False,
+               bea: Optional[_BeArena] = None):
     co = p[prefix + "body.0.weight"].shape[0]
-    y1 = pk.conv(prefix + "body.0.weight/f", x0, co, x1=x1)
+    # tables: [x of conv 1, x of conv 2 (a1), dy of conv 1, dy of conv 2]
+    be = [bea.take(x0.shape[0]) for _ in range(4)] if (save and bea is not None) else [None] * 4
+    y1 = pk.conv(prefix + "body.0.weight/f", x0, co, x1=x1, be_out=be[0])
     a1, st1, _ = ops.gn_silu_fwd(y1, p[prefix + "body.1.weight"], p[prefix + "body.1.bias"])
-    y2 = pk.conv(prefix + "body.3.weight/f", a1, co)
+    y2 = pk.conv(prefix + "body.3.weight/f", a1, co, be_out=be[1])
     a2, st2, pooled = ops.gn_silu_fwd(y2, p[prefix + "body.4.weight"], p[prefix + "body.4.bias"], want_pooled=True)
     res = ops.se_spatial_gate_fwd(a2, pooled, p[prefix + "se.fc.0.weight"], p[prefix + "se.fc.2.weight"],
                                   p[prefix + "spat.conv.weight"], pool_out=pool)
@@ -275,6 +294,7 @@ def _block_fwd(p: Params, pk, prefix: str, x0: Tensor, x1: Optional[Tensor], sav
         ctx = _BlockCtx()
         ctx.x0, ctx.x1, ctx.y1, ctx.a1, ctx.st1, ctx.y2, ctx.a2, ctx.st2 = x0, x1, y1, a1, st1, y2, a2, st2
         ctx.pooled, ctx.z, ctx.s, ctx.fmap, ctx.gate, ctx.out = pooled, z, s, fmap, gate, out
+        ctx.be = be
     if pool:
         return out, ctx, res[5]
     return out, ctx
@@ -293,15 +313,17 @@ def _block_bwd(p: Params, pk, g: Params, gw: Params, ss: "_SideStream", prefix: 
                                 ctx.gate, dmap, umax, cnt, ctx.s, dpool, g[prefix + "body.4.weight"],
                                 g[prefix + "body.4.bias"],
                                 se=(dsig, dz, ctx.z, ctx.pooled, g[prefix + "se.fc.0.weight"], g[prefix + "se.fc.2.weight"]))
-    ss.run(lambda: ops.wgrad3x3(ctx.a1, dy2, gw[prefix + "body.3.weight"]), ctx.a1, dy2)
-    da1 = pk.conv(prefix + "body.3.weight/d", dy2, co)
+    # (the data gradient first: it publishes the per-sample magnitudes of dy that the fp16x3 weight gradient scales by)
+    be = ctx.be
+    da1 = pk.conv(prefix + "body.3.weight/d", dy2, co, be_out=be[3])
+    ss.run(lambda: ops.wgrad3x3(ctx.a1, dy2, gw[prefix + "body.3.weight"], be_x=be[1], be_y=be[3]), ctx.a1, dy2)
     dy1 = ops.gn_silu_bwd(ctx.y1, p[prefix + "body.1.weight"], p[prefix + "body.1.bias"], ctx.st1, da1,
                           g[prefix + "body.1.weight"], g[prefix + "body.1.bias"])
     ci = ctx.x0.shape[1] + (0 if ctx.x1 is None else ctx.x1.shape[1])
-    ss.run(lambda: ops.wgrad3x3(ctx.x0, dy1, gw[prefix + "body.0.weight"], x1=ctx.x1), ctx.x0, ctx.x1, dy1)
-    if not need_dx:
-        return None
-    return pk.conv(prefix + "body.0.weight/d", dy1, ci)
+    dx = pk.conv(prefix + "body.0.weight/d", dy1, ci, be_out=be[2]) if need_dx else None
+    ss.run(lambda: ops.wgrad3x3(ctx.x0, dy1, gw[prefix + "body.0.weight"], x1=ctx.x1, be_x=be[0], be_y=be[2]),
+           ctx.x0, ctx.x1, dy1)
+    return dx
 
 
 def _zeros(*shape, device) -> Tensor:
@@ -400,10 +422,10 @@ class _Deferred:
 
 class _LstmCtx:
     """What the ConvLSTM backward needs from its forward."""
-    __slots__ = ("B", "T", "s4", "gx", "hprev", "call", "bott")
+    __slots__ = ("B", "T", "s4", "gx", "hprev", "call", "bott", "be")
 
 
-def convlstm_fwd(p: Params, pk, s4: Tensor, B: int, T: int, save: bool = True):
+def convlstm_fwd(p: Params, pk, s4: Tensor, B: int, T: int, save: bool = True, bea: Optional[_BeArena] = None):
     """ConvLSTM.forward (reference src/convlstm.py:27-35) on the folded encoder output s4 [B*T, Cx, h, w]
     (sample n = b*T + t).  Returns (h_last [B, Ch, h, w], ctx); ctx.hprev[:, t] = h_{t-1} (slot 0 = 0), so the hidden
     state of step t < T-1 is ctx.hprev[:, t+1] and the last one is h_last."""
@@ -411,19 +433,26 @@ def convlstm_fwd(p: Params, pk, s4: Tensor, B: int, T: int, save: bool = True):
     ch = wl.shape[0] // 4
     h8, w8 = s4.shape[2], s4.shape[3]
     dev = s4.device
-    gx = pk.conv("lstm.x/f", s4, 4 * ch, bias=bl).view(B, T, 4 * ch, h8, w8)
+    # exponent tables (sample n = b*T + t): [s4, h_{t-1}, d(pre-activations)]
+    be = [bea.take(B * T) for _ in range(3)] if (save and bea is not None) else [None] * 3
+    gx = pk.conv("lstm.x/f", s4, 4 * ch, bias=bl, be_out=be[0]).view(B, T, 4 * ch, h8, w8)
     hprev = _zeros(B, T, ch, h8, w8, device=dev)             # hprev[:, t] = h_{t-1}; slot 0 stays 0
     call = torch.empty(B, T, ch, h8, w8, device=dev, dtype=torch.float32)
     bott = torch.empty(B, ch, h8, w8, device=dev, dtype=torch.float32)
     for t in range(T):
         if t > 0:
-            pk.conv("lstm.h/f", hprev[:, t], 4 * ch, resid=gx[:, t], out=gx[:, t])
+            # (slot t of every sample's row of the [B, T] table: first entry t, stride T)
+            be_t = None if be[1] is None else ops.SampleExponents(be[1].t[t:], T)
+            pk.conv("lstm.h/f", hprev[:, t], 4 * ch, resid=gx[:, t], out=gx[:, t], be_out=be_t)
+            if be_t is not None:
+                be[1].valid = be_t.valid and (t == 1 or be[1].valid)
         ops.lstm_gates_fwd(gx[:, t], call[:, t - 1] if t > 0 else None, call[:, t],
                            hprev[:, t + 1] if t + 1 < T else bott)
     ctx = None
     if save:
         ctx = _LstmCtx()
         ctx.B, ctx.T, ctx.s4, ctx.gx, ctx.hprev, ctx.call, ctx.bott = B, T, s4, gx, hprev, call, bott
+        ctx.be = be
     return bott, ctx
 
 
@@ -462,20 +491,23 @@ def convlstm_bwd(p: Params, pk, g: Params, gw: Params, ss, ctx: _LstmCtx, dbott:
     dA = gx.view(B * T, 4 * ch, h8, w8)            # now holds d(pre-activations) for every (b, t)
     gl = gw["convlstm.cell.conv.weight"]
 
+    be = ctx.be
+    ds4 = pk.conv("lstm.x/d", dA, cx, be_out=be[2])       # (first: publishes the per-sample magnitudes of dA)
+
     def lstm_wgrads():
-        ops.wgrad3x3(ctx.s4, dA, gl, c_off=0)
-        if T > 1:
-            ops.wgrad3x3(hprev.view(B * T, ch, h8, w8), dA, gl, c_off=cx)   # hprev[:, 0] == 0 contributes nothing
+        ops.wgrad3x3(ctx.s4, dA, gl, c_off=0, be_x=be[0], be_y=be[2])
+        if T > 1:   # hprev[:, 0] == 0 contributes nothing
+            ops.wgrad3x3(hprev.view(B * T, ch, h8, w8), dA, gl, c_off=cx, be_x=be[1], be_y=be[2])
     ss.run(lstm_wgrads, ctx.s4, dA, hprev)
     ops.channel_sum(dA, g["convlstm.cell.conv.bias"])
-    return pk.conv("lstm.x/d", dA, cx)
+    return ds4
 
 
-def up_fwd(p: Params, pk, prefix: str, x: Tensor, skip: Tensor, save: bool = True):
+def up_fwd(p: Params, pk, prefix: str, x: Tensor, skip: Tensor, save: bool = True, bea: Optional[_BeArena] = None):
     """Up.forward (reference src/unet.py:66-69): ConvTranspose2d(2, s2) -> cat([up, skip]) -> ConvBlock; the concat is
     virtual.  Returns (out, (block ctx, x))."""
     u = ops.convT2x2_fwd(x, p[prefix + "up.weight"], p[prefix + "up.bias"])
-    out, ctx = _block_fwd(p, pk, prefix + "conv.", u, skip, save)
+    out, ctx = _block_fwd(p, pk, prefix + "conv.", u, skip, save, bea=bea)
     return out, (ctx, x)
 
 
@@ -510,23 +542,25 @@ def forward(p: Params, pk, x_seq: Tensor, save: bool = True, head: bool = True):
     sv = Saved() if save else None
 
     # ---- encoder, all frames at once -------------------------------------------------------------------
-    s1, c1, p1 = _block_fwd(p, pk, "enc1.", x, None, save, pool=True)     # Down = MaxPool2d(2) + ConvBlock
-    s2, c2, p2 = _block_fwd(p, pk, "enc2.conv.", p1, None, save, pool=True)
-    s3, c3, p3 = _block_fwd(p, pk, "enc3.conv.", p2, None, save, pool=True)
-    s4, c4 = _block_fwd(p, pk, "enc4.conv.", p3, None, save)
+    # per-sample exponent tables for the fp16x3 weight gradients: 4 per block, 3 for the ConvLSTM (one zero fill)
+    bea = _BeArena(x.device, 19 * B * T + 12 * B) if (save and ops.WGRAD_H3) else None
+    s1, c1, p1 = _block_fwd(p, pk, "enc1.", x, None, save, pool=True, bea=bea)     # Down = MaxPool2d(2) + ConvBlock
+    s2, c2, p2 = _block_fwd(p, pk, "enc2.conv.", p1, None, save, pool=True, bea=bea)
+    s3, c3, p3 = _block_fwd(p, pk, "enc3.conv.", p2, None, save, pool=True, bea=bea)
+    s4, c4 = _block_fwd(p, pk, "enc4.conv.", p3, None, save, bea=bea)
 
     # ---- time-mean skips (beside the recurrence when the side stream is on) + ConvLSTM bottleneck --------
     skips = []
     side = _SideStream(x.device, OVERLAP_LSTM)
     side.run(lambda: skips.extend(ops.time_mean(sk, B, T) for sk in (s1, s2, s3)), s1, s2, s3)
-    bott, lctx = convlstm_fwd(p, pk, s4, B, T, save)
+    bott, lctx = convlstm_fwd(p, pk, s4, B, T, save, bea=bea)
     side.join()
     k1, k2, k3 = skips
 
     # ---- decoder ---------------------------------------------------------------------------------------
-    d3, u3 = up_fwd(p, pk, "up3.", bott, k3, save)
-    d2, u2 = up_fwd(p, pk, "up2.", d3, k2, save)
-    d1, u1 = up_fwd(p, pk, "up1.", d2, k1, save)
+    d3, u3 = up_fwd(p, pk, "up3.", bott, k3, save, bea=bea)
+    d2, u2 = up_fwd(p, pk, "up2.", d3, k2, save, bea=bea)
+    d1, u1 = up_fwd(p, pk, "up1.", d2, k1, save, bea=bea)
     pred = ops.head_fwd(d1, p["head.weight"], p["head.bias"]) if head else None
 
     if save:
@@ -624,14 +658,15 @@ def unet_forward(p: Params, pk, x: Tensor, save: bool = True, head: bool = True)
     if H % 8 or W % 8:
         raise RuntimeError("H and W must be divisible by 8 (three 2x2 poolings)")
     x = x.contiguous()
-    s1, c1, p1 = _block_fwd(p, pk, "enc1.", x, None, save, pool=True)
-    s2, c2, p2 = _block_fwd(p, pk, "enc2.conv.", p1, None, save, pool=True)
-    s3, c3, p3 = _block_fwd(p, pk, "enc3.conv.", p2, None, save, pool=True)
-    s4, c4 = _block_fwd(p, pk, "enc4.conv.", p3, None, save)
-    bt, cb = _block_fwd(p, pk, "bott.", s4, None, save)
-    d3, u3 = up_fwd(p, pk, "up3.", bt, s3, save)
-    d2, u2 = up_fwd(p, pk, "up2.", d3, s2, save)
-    d1, u1 = up_fwd(p, pk, "up1.", d2, s1, save)
+    bea = _BeArena(x.device, 32 * B) if (save and ops.WGRAD_H3) else None
+    s1, c1, p1 = _block_fwd(p, pk, "enc1.", x, None, save, pool=True, bea=bea)
+    s2, c2, p2 = _block_fwd(p, pk, "enc2.conv.", p1, None, save, pool=True, bea=bea)
+    s3, c3, p3 = _block_fwd(p, pk, "enc3.conv.", p2, None, save, pool=True, bea=bea)
+    s4, c4 = _block_fwd(p, pk, "enc4.conv.", p3, None, save, bea=bea)
+    bt, cb = _block_fwd(p, pk, "bott.", s4, None, save, bea=bea)
+    d3, u3 = up_fwd(p, pk, "up3.", bt, s3, save, bea=bea)
+    d2, u2 = up_fwd(p, pk, "up2.", d3, s2, save, bea=bea)
+    d1, u1 = up_fwd(p, pk, "up1.", d2, s1, save, bea=bea)
     pred = ops.head_fwd(d1, p["head.weight"], p["head.bias"]) if head else None
     sv = None
     if save:

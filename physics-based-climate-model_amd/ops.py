@@ -117,8 +117,30 @@ SMALLC_CFG = 1 << 22   # tuned configuration id of the few-input-channels kernel
 LAST_CONV_CONFIG = -1   # configuration the most recent conv3x3() call ran with (the engine prunes unused weight packs)
 
 
+class SampleExponents:
+    """Per-sample biased exponents of max |x| ([n] int32, ``stride`` entries apart, zero-initialised by the owner) that a
+    cm_conv3x3_h3 launch publishes for the tensor it reads and cm_wgrad3x3_h3 consumes.  ``valid`` is set by the launch
+    wrapper: only the fp16x3 kernel publishes, and a consumer must not trust a table nobody wrote."""
+    __slots__ = ("t", "stride", "valid")
+
+    def __init__(self, t, stride=1):
+        self.t, self.stride, self.valid = t, int(stride), False
+
+    @staticmethod
+    def measure(x):
+        """Stand-alone measurement (one launch) for an x [N, C, H, W] no fp16x3 conv has read."""
+        n = x.shape[0]
+        se = SampleExponents(torch.zeros(n, device=x.device, dtype=torch.int32))
+        per = x[0].numel()
+        if x.dim() != 4 or x.stride(3) != 1 or x.stride(2) != x.shape[3] or x.stride(1) != x.shape[2] * x.shape[3]:
+            raise RuntimeError("SampleExponents.measure needs [N, C, H, W] with dense channel planes")
+        check(lib.cm_sample_exponents(_p(x), x.stride(0), n, per, _p_any(se.t), 1, _stream()), "sample_exponents")
+        se.valid = True
+        return se
+
+
 def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1, wps=None, w_raw=None,
-            out_zeroed=False, wph=None, winv=None):
+            out_zeroed=False, wph=None, winv=None, be_out=None):
     """out = conv3x3(cat(x0, x1), wp) + bias + resid.  x0/x1: [N,C,H,W] (sample stride may exceed C*H*W).
 
     ``wp`` is the fp32-MFMA operand (cm_pack_conv3x3); ``wps`` (optional) the bf16x6 operand of the same weight;
@@ -126,6 +148,7 @@ def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1, w
     (cm_conv3x3_smallc) to the candidates when cin * 9 <= 64.  ``out_zeroed``: the caller has filled ``out`` with
     zeros (one fill for several launches), so a K-split bf16x6 launch skips its own zero-fill launch.
     ``wph`` / ``winv`` (optional) the fp16x3 operand of the same weight and its inverse-scale scalar (pack_conv3x3_h3).
+    ``be_out`` (optional SampleExponents): filled with the per-sample magnitudes of the input when the fp16x3 kernel runs.
     With config < 0 the autotuner times every kernel family it has an operand for on this call signature and keeps
     the fastest."""
     n, c0, h, w = x0.shape
@@ -145,7 +168,8 @@ def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1, w
                                              _scratch[0].stride(0), n, h, w, cout, _stream())
             if cfg >= H3_BASE:
                 return lib.cm_conv3x3_h3(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(wph), _p(winv), _p(bias), None, 0,
-                                         _p(_scratch[0]), _scratch[0].stride(0), n, h, w, cout, cfg - H3_BASE, _stream())
+                                         _p(_scratch[0]), _scratch[0].stride(0), None, 0, n, h, w, cout, cfg - H3_BASE,
+                                         _stream())
             if cfg >= SPLIT_BASE:
                 return lib.cm_conv3x3_split(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(wps), _p(bias), None, 0,
                                             _p(_scratch[0]), _scratch[0].stride(0), n, h, w, cout, cfg - SPLIT_BASE,
@@ -202,8 +226,11 @@ def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1, w
         if out_zeroed and (cfg >> 8) > 1:
             cfg |= 1 << 30
         check(lib.cm_conv3x3_h3(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(wph), _p(winv), _p(bias), _p(resid),
-                                0 if resid is None else resid.stride(0), _p(out), out.stride(0), n, h, w, cout, cfg,
-                                _stream()), "conv3x3_h3")
+                                0 if resid is None else resid.stride(0), _p(out), out.stride(0),
+                                None if be_out is None else _p_any(be_out.t), 0 if be_out is None else be_out.stride,
+                                n, h, w, cout, cfg, _stream()), "conv3x3_h3")
+        if be_out is not None:
+            be_out.valid = True
         return out
     if config >= SPLIT_BASE:
         cfg = config - SPLIT_BASE
@@ -262,21 +289,20 @@ def conv3x3_split(x0, wps, cout, x1=None, bias=None, resid=None, out=None, confi
     return out
 
 
-# Matrix-core numerics of the WEIGHT GRADIENT: bf16x6 by default, also under CM_CONV_NUMERICS=fp16x3.  The fp16x3 form
-# (cm_wgrad3x3_h3, CM_WGRAD_NUMERICS=fp16x3) is exact to 2e-6 whenever the magnitudes inside one 8-sample group stay
-# within ~2^28 of each other, but its reduction mixes samples under ONE power-of-two scale per staged row: the
-# reference's left-padded windows put exactly-zero activations next to gradients amplified by rstd = 1/sqrt(eps) = 316
-# per GroupNorm (zero frames), which pushes the real frames' gradients > 2^28 below the row maximum and cost 5.7 % on
-# enc1.body.3.weight at BASELINE config 2's size.  bf16's 8 exponent bits need no scale.  (The convolutions do not have
-# this problem: a GEMM column is one sample's pixel, so cm_conv3x3_h3 scales per sample.)
-_WG_NUM = os.environ.get("CM_WGRAD_NUMERICS", "fp32" if os.environ.get("CM_CONV_NUMERICS") == "fp32" else "bf16x6")
+# Matrix-core numerics of the WEIGHT GRADIENT (CM_WGRAD_NUMERICS): follows the convolutions -- fp16x3 by default, bf16x6
+# under CM_CONV_NUMERICS=bf16x6, fp32 under fp32.  The reduction of a weight gradient mixes samples, and the reference's
+# left-padded windows put all-zero frames (gradients amplified by rstd = 1/sqrt(eps) = 316 per GroupNorm) next to real
+# ones, 2^28 apart: cm_wgrad3x3_h3 therefore scales PER SAMPLE with a constant product scale (csrc/wgrad3x3_split.hip),
+# fed by the per-sample magnitudes the fp16x3 convolutions publish for the tensors they read (SampleExponents).
+_cn = os.environ.get("CM_CONV_NUMERICS", "fp16x3")
+_WG_NUM = os.environ.get("CM_WGRAD_NUMERICS", _cn if _cn in ("fp16x3", "bf16x6", "fp32") else "bf16x6")
 if _WG_NUM not in ("fp16x3", "bf16x6", "fp32"):
     raise RuntimeError(f"CM_WGRAD_NUMERICS={_WG_NUM!r}: expected fp16x3, bf16x6 or fp32")
 WGRAD_BF16X6 = _WG_NUM == "bf16x6"
 WGRAD_H3 = _WG_NUM == "fp16x3"
 
 
-def _wgrad_call(x0, dy, g, c_off, x1, config):
+def _wgrad_call(x0, dy, g, c_off, x1, config, be_x=None, be_y=None):
     """One launch of a weight-gradient family: ids >= SPLIT_BASE select the bf16x6 kernel (cm_wgrad3x3_split),
     SMALLC_CFG the first-layer kernel (cm_wgrad3x3_smallc)."""
     n, c0, h, w = x0.shape
@@ -288,7 +314,8 @@ def _wgrad_call(x0, dy, g, c_off, x1, config):
         return lib.cm_wgrad3x3_smallc(_p(x0), x0.stride(0), c0, _p(dy), dy.stride(0), _p(g), ctot, c_off, n, h, w, cout,
                                       _p(ws), _stream())
     if config >= H3_BASE:
-        fn, cfg = lib.cm_wgrad3x3_h3, config - H3_BASE
+        return lib.cm_wgrad3x3_h3(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(dy), dy.stride(0), _p_any(be_x.t), _p_any(be_y.t),
+                                  _p(g), ctot, c_off, n, h, w, cout, config - H3_BASE, _stream())
     elif config >= SPLIT_BASE:
         fn, cfg = lib.cm_wgrad3x3_split, config - SPLIT_BASE
     else:
@@ -297,19 +324,35 @@ def _wgrad_call(x0, dy, g, c_off, x1, config):
               _stream())
 
 
-def wgrad3x3(x0, dy, g, c_off=0, x1=None, config=-1):
+def wgrad3x3(x0, dy, g, c_off=0, x1=None, config=-1, be_x=None, be_y=None):
     """g[cout][9][ctot] += wgrad(cat(x0, x1), dy) for input-channel range [c_off, ...).
+
+    ``be_x`` / ``be_y`` (SampleExponents, optional): per-sample magnitudes of cat(x0, x1) / dy for the fp16x3 kernel,
+    normally published by the conv launches that read the same tensors; measured here (one launch each) when missing.
 
     With config < 0 the autotuner times the fp32-MFMA and (unless CM_WGRAD_BF16X6=0) the bf16x6 configurations on this
     call signature and keeps the fastest."""
     n, c0, h, w = x0.shape
     c1 = 0 if x1 is None else x1.shape[1]
     cout = g.shape[0]
+    be = [be_x, be_y]
+
+    def tables():
+        """Per-sample magnitudes for the fp16x3 kernel: the published ones, or measured here (one launch per operand)."""
+        if be[0] is None or not be[0].valid or be[0].stride != 1:
+            be[0] = SampleExponents.measure(x0)
+            if x1 is not None:
+                check(lib.cm_sample_exponents(_p(x1), x1.stride(0), n, x1[0].numel(), _p_any(be[0].t), 1, _stream()),
+                      "sample_exponents")
+        if be[1] is None or not be[1].valid or be[1].stride != 1:
+            be[1] = SampleExponents.measure(dy)
+        return be
     if config < 0:
         def launch(cfg, _scratch=[None]):
             if _scratch[0] is None:
                 _scratch[0] = torch.empty_like(g)
-            return _wgrad_call(x0, dy, _scratch[0], c_off, x1, cfg)
+            return _wgrad_call(x0, dy, _scratch[0], c_off, x1, cfg, *(tables() if cfg >= H3_BASE and cfg != SMALLC_CFG
+                                                                       else (None, None)))
         cands = [c + (u << 8) for c in range(lib.cm_wgrad3x3_num_configs()) for u in (2, 3, 4, 6, 8)]
         if (WGRAD_BF16X6 or WGRAD_H3) and (c1 == 0 or c0 % 32 == 0):
             base = H3_BASE if WGRAD_H3 else SPLIT_BASE
@@ -317,7 +360,9 @@ def wgrad3x3(x0, dy, g, c_off=0, x1=None, config=-1):
         if c1 == 0 and c0 * 9 <= 64 and w % 4 == 0 and w <= 320 and dy.stride(0) % 4 == 0:
             cands.append(SMALLC_CFG)
         config = _pick(("wgrad3x3", n, h, w, c0, c1, cout, _WG_NUM), cands, launch, -1)
-    check(_wgrad_call(x0, dy, g, c_off, x1, config), "wgrad3x3")
+    if config >= H3_BASE and config != SMALLC_CFG:
+        tables()
+    check(_wgrad_call(x0, dy, g, c_off, x1, config, be[0], be[1]), "wgrad3x3")
     return g
 
 

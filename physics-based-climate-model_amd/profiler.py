@@ -18,12 +18,12 @@ def _conv_bytes(a):
     return 4.0 * (n * h * w * (cin + cout) + 9 * cin * cout)
 
 
-def _conv_h3_flops(a):     # cm_conv3x3_h3(in0, st0, c0, in1, st1, c1, wps, winv, bias, resid, st_resid, out, st_out, n, h, w, cout, ..)
-    return 2.0 * a[13] * a[14] * a[15] * a[16] * (a[2] + a[5]) * 9
+def _conv_h3_flops(a):     # cm_conv3x3_h3(in0, st0, c0, in1, st1, c1, wps, winv, bias, resid, st_resid, out, st_out, be, be_stride, n, h, w, cout, ..)
+    return 2.0 * a[15] * a[16] * a[17] * a[18] * (a[2] + a[5]) * 9
 
 
 def _conv_h3_bytes(a):
-    n, h, w, cout, cin = a[13], a[14], a[15], a[16], a[2] + a[5]
+    n, h, w, cout, cin = a[15], a[16], a[17], a[18], a[2] + a[5]
     return 4.0 * (n * h * w * (cin + cout) + 9 * cin * cout)
 
 
@@ -45,11 +45,19 @@ def _lstm_bwd_bytes(a):    # (gates, sg, c_prev, scp, c_cur, scc, dh_a, sa, dh_b
     return 4.0 * a[12] * a[13] * a[14] * (reads + 5)
 
 
+def _wgrad_h3_flops(a):    # cm_wgrad3x3_h3(x0, sx0, c0, x1, sx1, c1, dy, sdy, be_x, be_y, g, ctot, c_off, n, h, w, cout, config, stream)
+    return _wgrad_flops(a[:8] + a[10:])
+
+
+def _wgrad_h3_bytes(a):
+    return _wgrad_bytes(a[:8] + a[10:])
+
+
 MODELS = {
     "cm_conv3x3": (_conv_flops, _conv_bytes),
     "cm_conv3x3_split": (_conv_flops, _conv_bytes),     # same argument positions; ALGORITHMIC flops (x6 are executed)
     "cm_conv3x3_h3": (_conv_h3_flops, _conv_h3_bytes),  # ALGORITHMIC flops (x3 are executed)
-    "cm_wgrad3x3_h3": (_wgrad_flops, _wgrad_bytes),
+    "cm_wgrad3x3_h3": (_wgrad_h3_flops, _wgrad_h3_bytes),
     "cm_wgrad3x3": (_wgrad_flops, _wgrad_bytes),
     "cm_wgrad3x3_split": (_wgrad_flops, _wgrad_bytes),  # same argument positions; ALGORITHMIC flops
     "cm_lstm_gates_fwd": (None, _lstm_fwd_bytes),

@@ -606,7 +606,7 @@ def _conv_h3(ops, x0, wph, winv, cout, x1=None, bias=None, resid=None, config=0)
                             0 if x1 is None else x1.stride(0), 0 if x1 is None else x1.shape[1], wph.data_ptr(),
                             winv.data_ptr(), None if bias is None else bias.data_ptr(),
                             None if resid is None else resid.data_ptr(), 0 if resid is None else resid.stride(0),
-                            out.data_ptr(), out.stride(0), n, h, w, cout, config,
+                            out.data_ptr(), out.stride(0), None, 0, n, h, w, cout, config,
                             torch.cuda.current_stream().cuda_stream), "conv3x3_h3")
     return out
 
@@ -753,3 +753,89 @@ def test_conv3x3_fp16x3_sample_groups(ops):
         assert torch.isfinite(y).all(), cfg
         for s in range(n):
             assert rel_l2(y[s], ref[s]) < 2e-6, (cfg, s, rel_l2(y[s], ref[s]))
+
+
+def _biased_exponents(x):
+    m = x.abs().flatten(1).amax(1).float()
+    return (m.view(torch.int32) >> 23) & 0xff
+
+
+def test_conv3x3_fp16x3_publishes_sample_exponents(ops):
+    """cm_conv3x3_h3's sample_be output (what the fp16x3 weight gradient scales by): exact biased exponent of every
+    sample's max |input| over BOTH input tensors -- every tile configuration (sample groups, 8 waves), reduction splits,
+    a strided table (the ConvLSTM's [B, T] layout) -- and equal to the stand-alone cm_sample_exponents."""
+    n, c0, c1, co, h, w = 13, 32, 16, 32, 12, 18
+    x0 = rnd(n, c0, h, w, seed=131); x1 = rnd(n, c1, h, w, seed=132)
+    mags = torch.tensor([1e-30, 1e-12, 3e-5, 1.0, 7.0, 1e4, 1e19, 0.0, 2.0 ** -126, 1.0, 1.0, 1.0, 1e-3])
+    x0 = x0 * mags.view(-1, 1, 1, 1)
+    x1 = x1 * mags.flip(0).view(-1, 1, 1, 1)
+    x1[9, 3, 5, 5] = 6e5                                   # a single large element in the second tensor
+    want = torch.maximum(_biased_exponents(x0), _biased_exponents(x1))
+    wt = rnd(co, c0 + c1, 3, 3, seed=133, scale=0.05)
+    wph, winv = ops.pack_conv3x3_h3(dev(wt))
+    xd0, xd1 = dev(x0), dev(x1)
+    for cfg in (0, 3, 4, 9, 13, 15, 18, 27, 0 + (2 << 8), 3 + (2 << 8)):
+        se = ops.SampleExponents(torch.zeros(n, device="cuda", dtype=torch.int32))
+        out = torch.zeros(n, co, h, w, device="cuda")
+        ops.conv3x3(xd0, None, co, x1=xd1, out=out, wph=wph, winv=winv, config=ops.H3_BASE + cfg, out_zeroed=True, be_out=se)
+        assert se.valid and torch.equal(se.t.cpu(), want), (cfg, se.t.cpu(), want)
+    # strided table + images that share a workgroup (6x9, S = 2..6)
+    n, c, h, w, T = 12, 32, 6, 9, 3
+    x = rnd(n, c, h, w, seed=134) * torch.logspace(-20, 20, n).view(-1, 1, 1, 1)
+    wph, winv = ops.pack_conv3x3_h3(dev(rnd(co, c, 3, 3, seed=135, scale=0.05)))
+    for cfg in (5, 7, 17, 20, 22):
+        tab = torch.zeros(n, T, device="cuda", dtype=torch.int32)
+        se = ops.SampleExponents(tab.view(-1)[1:], T)
+        ops.conv3x3(dev(x), None, co, wph=wph, winv=winv, config=ops.H3_BASE + cfg, be_out=se)
+        assert torch.equal(tab[:, 1].cpu(), _biased_exponents(x)), cfg
+        assert not tab[:, 0].any() and not tab[:, 2].any()
+    m = ops.SampleExponents.measure(dev(x))
+    assert m.valid and torch.equal(m.t.cpu(), _biased_exponents(x))
+
+
+@pytest.mark.parametrize("spread", [0, 20, 60])
+def test_wgrad3x3_fp16x3_per_sample_scales(ops, spread):
+    """The reduction of a weight gradient mixes samples.  Samples whose operands differ by 2^+-spread in OPPOSITE
+    directions (x_s * 2^k, dy_s * 2^-k: every sample contributes equally to the result, as a left-padded frame's
+    amplified gradient times its small activations does) must all survive: one scale per 8-sample record group -- the
+    round-1 scheme -- flushes the small operands to zero."""
+    n, ci, co, h, w = 16, 32, 32, 12, 18
+    x = rnd(n, ci, h, w, seed=141)
+    dy = rnd(n, co, h, w, seed=142)
+    k = torch.linspace(-spread, spread, n).round()
+    k = k[torch.randperm(n, generator=torch.Generator().manual_seed(1))]
+    x = x * (2.0 ** k).view(-1, 1, 1, 1)
+    dy = dy * (2.0 ** -k).view(-1, 1, 1, 1)
+    wt = torch.zeros(co, ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wt, padding=1).backward(dy.double())
+    # every sample matters: dropping any one of them changes the result by ~1/sqrt(n)
+    for i in (0, 4, 9, 12):
+        g = torch.zeros(co, 9, ci, device="cuda")
+        ops.wgrad3x3(dev(x), dev(dy), g, config=ops.H3_BASE + i + (2 << 8))
+        err = rel_l2(ops.wgrad3x3_unpack(g), wt.grad)
+        assert err < 2e-6, (i, err)
+
+
+def test_wgrad3x3_fp16x3_small_products_next_to_large(ops):
+    """A sample whose products are 2^-30 of the largest sample's keeps full RELATIVE accuracy in its own contribution:
+    checked by linearity -- wgrad(all samples) - wgrad(large samples only) == wgrad(small samples only), to the noise of
+    the large ones (2^-22 of THEIR contribution bounds what any fp32 sum can resolve)."""
+    n, ci, co, h, w = 8, 32, 32, 6, 9
+    x = rnd(n, ci, h, w, seed=151)
+    dy = rnd(n, co, h, w, seed=152)
+    dy[:2] *= 2.0 ** 12
+    x[:2] *= 2.0 ** 8                                       # samples 0, 1: products 2^20 above the others
+    wt = torch.zeros(co, ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x[2:].double(), wt, padding=1).backward(dy[2:].double())
+    small_only = wt.grad.clone()
+    g = torch.zeros(co, 9, ci, device="cuda")
+    xs, dys = x.clone(), dy.clone()
+    xs[:2] = 0.0
+    ops.wgrad3x3(dev(xs), dev(dys), g, config=ops.H3_BASE + (2 << 8))
+    assert rel_l2(ops.wgrad3x3_unpack(g), small_only) < 2e-6      # zero samples beside them: exact scaling of the rest
+    # with the large samples present the small ones are scaled 10 bits down each: still 22 - 0 bits (fp16 is a FLOAT)
+    g2 = torch.zeros(co, 9, ci, device="cuda")
+    ops.wgrad3x3(dev(x), dev(dy), g2, config=ops.H3_BASE + (2 << 8))
+    wt2 = torch.zeros(co, ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wt2, padding=1).backward(dy.double())
+    assert rel_l2(ops.wgrad3x3_unpack(g2), wt2.grad) < 2e-6

@@ -18,7 +18,7 @@ def conv_h3(x0, wph, winv, co, x1, out, cfg):
     n, c0, h, w = x0.shape
     return lib.cm_conv3x3_h3(x0.data_ptr(), x0.stride(0), c0, None if x1 is None else x1.data_ptr(),
                              0 if x1 is None else x1.stride(0), 0 if x1 is None else x1.shape[1], wph.data_ptr(),
-                             winv.data_ptr(), None, None, 0, out.data_ptr(), out.stride(0), n, h, w, co, cfg,
+                             winv.data_ptr(), None, None, 0, out.data_ptr(), out.stride(0), None, 0, n, h, w, co, cfg,
                              torch.cuda.current_stream().cuda_stream)
 
 
