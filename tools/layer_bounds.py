@@ -50,7 +50,11 @@ for name, n, c0, c1, co, h, w in layers(a.base, a.B, a.T):
     else:
         row += "               |"
     g = torch.zeros(co, 9, ci, device="cuda")
-    f = lambda: ops.wgrad3x3(x0, dy, g, x1=x1)
+    bx = by = None
+    if ops.WGRAD_H3:        # (in the engine the fp16x3 convs publish these while reading the same tensors)
+        bx = ops.SampleExponents.measure(torch.cat([x0, x1], 1) if x1 is not None else x0)
+        by = ops.SampleExponents.measure(dy)
+    f = lambda: ops.wgrad3x3(x0, dy, g, x1=x1, be_x=bx, be_y=by)
     f(); t = timeit(f, 10); tot["wgrad"] += t
     mbw = wprod * flops / 2.5e15 * 1e6
     tot["bwgrad"] += max(hb, mbw)
