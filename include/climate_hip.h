@@ -270,10 +270,14 @@ int cm_eval_finalize(const double* moments, const double* lat_w_dev, double coun
  * trans_a = 0: A stored [m][k] (lda); 1: stored [k][m].  trans_b = 0: B stored [n][k] (ldb) -- an nn.Linear weight
  * [out][in], so C = A W^T (F.linear: nn.TransformerEncoderLayer's in_proj / out_proj / linear1 / linear2,
  * src/cnn_transformer.py:26-33) --; 1: stored [k][n].  ksplit > 1: K split over workgroups, raw sums accumulated with
- * atomics into a C the caller zeroed (weight gradients: C = dY^T X with trans_a = trans_b = 1).                   */
+ * atomics into a C the caller zeroed (weight gradients: C = dY^T X with trans_a = trans_b = 1).
+ * Dropout (nn.Dropout in the encoder layer, src/cnn_transformer.py:26-33): with rng != null and drop_p > 0 the value is
+ * multiplied by the counter-based mask of (rng, site) -- see cm_dropout -- after bias / ReLU and BEFORE the residual
+ * (x + dropout(sublayer(x))); mask_scale multiplies what `mask` keeps (ReLU backward through a dropped activation).  */
 int cm_gemm_h3(const float* a, long long lda, int trans_a, const float* b, long long ldb, int trans_b, float* c,
                long long ldc, const float* bias, const float* resid, long long ldr, int res_rows, const float* mask,
-               long long ldm, int relu, int m, int n, int k, int ksplit, cm_stream stream);
+               long long ldm, float mask_scale, int relu, const unsigned* rng, unsigned site, float drop_p, int m, int n,
+               int k, int ksplit, cm_stream stream);
 /* post-norm residual LayerNorm, eps as given (nn.LayerNorm default 1e-5): sum_out = x + resid (nullable resid; kept for
  * the backward), y = LN(sum_out) * gamma + beta, stats[m][2] = {mean, rstd}.  e <= 1024.                          */
 int cm_layernorm_fwd(const float* x, const float* resid, const float* gamma, const float* beta, float* sum_out, float* y,
@@ -284,10 +288,20 @@ int cm_layernorm_bwd(const float* sum_in, const float* stats, const float* gamma
 /* Multi-head self-attention core of nn.MultiheadAttention (batch_first, no mask, dropout off): qkv [b*s, 3e] = packed
  * in_proj output; p [b, h, s, s] = softmax(q k^T / sqrt(d)) (kept for the backward); o [b*s, e] = p v, heads
  * concatenated.  head_dim e/h in {8, 16, 32}, s <= 256.                                                           */
-int cm_attention_fwd(const float* qkv, float* p, float* o, int b, int s, int e, int h, cm_stream stream);
-/* dqkv [b*s, 3e] (all three column blocks written) from d_o [b*s, e]; ds_scratch [b, h, s, s] workspace.          */
-int cm_attention_bwd(const float* qkv, const float* p, const float* d_o, float* ds_scratch, float* dqkv, int b, int s,
+/* rng / site / drop_p: dropout on the attention probabilities (nn.MultiheadAttention(dropout=p)); p holds the UNdropped
+ * probabilities, the mask is regenerated from the element index by the backward.  drop_p = 0: off.                   */
+int cm_attention_fwd(const float* qkv, float* p, float* o, const unsigned* rng, unsigned site, float drop_p, int b, int s,
                      int e, int h, cm_stream stream);
+/* dqkv [b*s, 3e] (all three column blocks written) from d_o [b*s, e]; ds_scratch [b, h, s, s] workspace.          */
+int cm_attention_bwd(const float* qkv, const float* p, const float* d_o, float* ds_scratch, float* dqkv,
+                     const unsigned* rng, unsigned site, float drop_p, int b, int s, int e, int h, cm_stream stream);
+/* Counter-based dropout: out[i] = in[i] * (hash(i ^ key(rng[0] = seed, rng[1] = step counter, site)) < p * 2^32 ? 0 :
+ * 1 / (1 - p)).  Nothing is stored: every consumer regenerates the decision from the element index (row-major index of
+ * the logical [m, n] GEMM output; flat [b, h, s, s] index for attention probabilities).  cm_rng_advance: counter += 1,
+ * once per training forward, on the device so that a replayed hipGraph draws fresh masks.  The stream is NOT torch's
+ * Philox stream: masks match the reference statistically, not bitwise.                                 */
+int cm_dropout(const float* in, float* out, long long n, const unsigned* rng, unsigned site, float p, cm_stream stream);
+int cm_rng_advance(unsigned* rng, cm_stream stream);
 /* nn.Conv2d(cin, cout, 3, stride=2, padding=1) as im2col + cm_gemm_h3 (src/cnn_transformer.py:9-13): col
  * [b*(h/2)*(w/2)][ldc], column ci*9 + tap, zero beyond cin*9; x NCHW (tokens_in = 0) or token-major [b*h*w][cin].
  * cm_col2im_s2: the data gradient, token-major out.                                                                */

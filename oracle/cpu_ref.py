@@ -358,8 +358,12 @@ def closed_form_params(in_ch: int, out_ch: int, base: int, dtype=torch.float32, 
 
 
 # ----------------------------------------------------------------------------- cnn_transformer (BASELINE config 4)
-def cnn_transformer_forward(p: Params, x: Tensor, n_heads: int) -> Tensor:
-    """CNNTransformer.forward (src/cnn_transformer.py:44-54) with dropout OFF (eval mode / p = 0), spelled out with
+def cnn_transformer_forward(p: Params, x: Tensor, n_heads: int, masks=None) -> Tensor:
+    """CNNTransformer.forward (src/cnn_transformer.py:44-54), dropout OFF (eval mode / p = 0) unless ``masks`` is given:
+    masks[(layer, k)] = the multiplier tensor (0 or 1 / (1 - p)) of dropout site k of that layer -- 0: attention
+    probabilities [B, H, S, S] (nn.MultiheadAttention(dropout)), 1: after the attention block [B, S, E], 2: inside the
+    MLP after the ReLU [B, S, mlp], 3: after the MLP [B, S, E] (nn.TransformerEncoderLayer._sa_block / _ff_block) --
+    so that a test can impose another implementation's masks.  Spelled out with
     functional ops: two stride-2 3x3 convs + ReLU -> 216 tokens + learned positional embedding -> ``depth`` post-norm
     nn.TransformerEncoderLayer (batch_first, ReLU MLP, eps 1e-5) -> two 2x2 stride-2 transposed convs + ReLU -> 1x1.
     Parameter names are the reference's state_dict keys."""
@@ -374,12 +378,21 @@ def cnn_transformer_forward(p: Params, x: Tensor, n_heads: int) -> Tensor:
         q = f"transformer.layers.{i}."
         qkv = F.linear(t, p[q + "self_attn.in_proj_weight"], p[q + "self_attn.in_proj_bias"])
         qh, kh, vh = (z.reshape(b, -1, n_heads, d).transpose(1, 2) for z in qkv.chunk(3, dim=-1))   # [B, H, S, d]
+        mk = (lambda k: None) if masks is None else (lambda k: masks.get((i, k)))
         att = torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(d), dim=-1)
+        if mk(0) is not None:
+            att = att * mk(0)
         o = (att @ vh).transpose(1, 2).reshape(b, -1, e)
         o = F.linear(o, p[q + "self_attn.out_proj.weight"], p[q + "self_attn.out_proj.bias"])
+        if mk(1) is not None:
+            o = o * mk(1)
         t = F.layer_norm(t + o, (e,), p[q + "norm1.weight"], p[q + "norm1.bias"], 1e-5)
-        m = F.linear(F.relu(F.linear(t, p[q + "linear1.weight"], p[q + "linear1.bias"])),
-                     p[q + "linear2.weight"], p[q + "linear2.bias"])
+        hdn = F.relu(F.linear(t, p[q + "linear1.weight"], p[q + "linear1.bias"]))
+        if mk(2) is not None:
+            hdn = hdn * mk(2)
+        m = F.linear(hdn, p[q + "linear2.weight"], p[q + "linear2.bias"])
+        if mk(3) is not None:
+            m = m * mk(3)
         t = F.layer_norm(t + m, (e,), p[q + "norm2.weight"], p[q + "norm2.bias"], 1e-5)
     y = t.transpose(1, 2).reshape(b, e, hh, ww)
     y = F.relu(F.conv_transpose2d(y, p["decoder.0.weight"], p["decoder.0.bias"], stride=2))

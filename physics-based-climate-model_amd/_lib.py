@@ -30,6 +30,7 @@ _CTYPES = {
     "const int*": ctypes.c_void_p,
     "int*": ctypes.c_void_p,
     "const long long*": ctypes.c_void_p,
+    "unsigned": ctypes.c_uint,
     "unsigned*": ctypes.c_void_p,
     "const unsigned*": ctypes.c_void_p,
     "double": ctypes.c_double,

@@ -14,9 +14,12 @@ Schedule (every contraction on the f16 matrix cores with fp32-equivalent accurac
 Backward: the same kernels' gradient forms (weight gradients are split-K GEMMs accumulating straight into the flat
 gradient buffer).
 
-DROPOUT: the reference trains this model with ``dropout=0.1`` (four sites per layer).  This path implements the
-dropout-free function -- ``model.eval()`` or ``dropout=0`` -- which is what the parity fixtures pin; calling it in
-training mode with ``dropout > 0`` raises instead of silently dropping the regulariser.
+DROPOUT: the reference trains this model with ``dropout=0.1`` -- four sites per encoder layer (attention
+probabilities, after the attention block, inside the MLP, after the MLP).  In training mode the kernels apply
+counter-based masks (csrc/common.h: a hash of seed, step counter, site and element index; nothing is stored, the backward
+regenerates them; the counter lives on the device so a replayed hipGraph draws fresh masks every step).  The masks are
+the reference's in distribution, not bit for bit (torch's Philox stream is not reproduced): the parity tests export the
+device's masks, apply them in the oracle and compare every gradient; ``eval()`` is the dropout-free function.
 """
 import math
 from typing import Dict
@@ -34,8 +37,13 @@ class _Saved:
     pass
 
 
-def forward(p: Dict[str, Tensor], x: Tensor, n_heads: int, save: bool = True, head: bool = True):
-    """x [B, Cin, H, W] (H, W multiples of 4) -> pred [B, out, H, W], saved activations."""
+def forward(p: Dict[str, Tensor], x: Tensor, n_heads: int, save: bool = True, head: bool = True, drop=None):
+    """x [B, Cin, H, W] (H, W multiples of 4) -> pred [B, out, H, W], saved activations.
+
+    ``drop`` = (rng, p) turns on the four dropouts of every encoder layer (attention probabilities, after the attention
+    block, inside the MLP, after the MLP: nn.TransformerEncoderLayer(dropout=p), reference src/cnn_transformer.py:26-33)
+    with counter-based masks: site 4*layer + {0, 1, 2, 3}; rng is this call's {seed, counter} snapshot (kept in the
+    saved state: the backward regenerates the masks from it)."""
     if x.dim() != 4:
         raise RuntimeError("expected x of shape [B, C, H, W]")
     B, Cin, H, W = x.shape
@@ -61,12 +69,13 @@ def forward(p: Dict[str, Tensor], x: Tensor, n_heads: int, save: bool = True, he
     for i in range(depth):
         q = f"transformer.layers.{i}."
         mlp = p[q + "linear1.weight"].shape[0]
+        dr = [None] * 4 if drop is None else [(drop[0], 4 * i + k, drop[1]) for k in range(4)]
         qkv = ops.gemm(t, p[q + "self_attn.in_proj_weight"], M, 3 * E, E, bias=p[q + "self_attn.in_proj_bias"])
-        P, o = ops.attention_fwd(qkv, B, S, E, n_heads)
-        a = ops.gemm(o, p[q + "self_attn.out_proj.weight"], M, E, E, bias=p[q + "self_attn.out_proj.bias"])
+        P, o = ops.attention_fwd(qkv, B, S, E, n_heads, drop=dr[0])
+        a = ops.gemm(o, p[q + "self_attn.out_proj.weight"], M, E, E, bias=p[q + "self_attn.out_proj.bias"], drop=dr[1])
         t1, s1, st1 = ops.layernorm_fwd(a, t, p[q + "norm1.weight"], p[q + "norm1.bias"])
-        h1 = ops.gemm(t1, p[q + "linear1.weight"], M, mlp, E, bias=p[q + "linear1.bias"], relu=True)
-        m2 = ops.gemm(h1, p[q + "linear2.weight"], M, E, mlp, bias=p[q + "linear2.bias"])
+        h1 = ops.gemm(t1, p[q + "linear1.weight"], M, mlp, E, bias=p[q + "linear1.bias"], relu=True, drop=dr[2])
+        m2 = ops.gemm(h1, p[q + "linear2.weight"], M, E, mlp, bias=p[q + "linear2.bias"], drop=dr[3])
         t2, s2, st2 = ops.layernorm_fwd(m2, t1, p[q + "norm2.weight"], p[q + "norm2.bias"])
         if save:
             layers.append((t, qkv, P, o, s1, st1, t1, h1, s2, st2))
@@ -81,6 +90,7 @@ def forward(p: Dict[str, Tensor], x: Tensor, n_heads: int, save: bool = True, he
         sv.shape, sv.col1, sv.y1, sv.col2, sv.t0, sv.layers, sv.z = (B, Cin, H, W), col1, y1, col2, t0, layers, z
         sv.dec1, sv.dec2 = d1, d2         # decoder activations (post-ReLU)
         sv.d1 = d2                        # input of the 1x1 head: what the fused trainer's head+MSE launch reads
+        sv.drop = drop
     return pred, sv
 
 
@@ -117,18 +127,25 @@ def backward(p: Dict[str, Tensor], g: Dict[str, Tensor], sv, n_heads: int, dpred
         q = f"transformer.layers.{i}."
         t_in, qkv, P, o, s1, st1, t1, h1, s2, st2 = sv.layers[i]
         mlp = h1.shape[1]
+        drop = getattr(sv, "drop", None)
+        dr = [None] * 4 if drop is None else [(drop[0], 4 * i + k, drop[1]) for k in range(4)]
+        keep_scale = 1.0 if drop is None else 1.0 / (1.0 - drop[1])
         ds2 = ops.layernorm_bwd(s2, st2, p[q + "norm2.weight"], dt, g[q + "norm2.weight"], g[q + "norm2.bias"])
-        ops.rowgroup_sum(ds2, g[q + "linear2.bias"].view(1, E))
-        _wgrad(ds2, h1, g[q + "linear2.weight"], E, mlp, M)
-        dh1 = ops.gemm(ds2, p[q + "linear2.weight"], M, mlp, E, trans_b=True, mask=h1)        # through linear2 and the ReLU
+        # ds2 = gradient wrt (t1 + dropout(m2)): the residual branch takes it as it is, the MLP branch through the mask
+        dm2 = ds2 if drop is None else ops.dropout(ds2, dr[3])
+        ops.rowgroup_sum(dm2, g[q + "linear2.bias"].view(1, E))
+        _wgrad(dm2, h1, g[q + "linear2.weight"], E, mlp, M)
+        # through linear2, the MLP dropout and the ReLU: h1 is the DROPPED activation, so h1 > 0 <=> kept and positive
+        dh1 = ops.gemm(dm2, p[q + "linear2.weight"], M, mlp, E, trans_b=True, mask=h1, mask_scale=keep_scale)
         ops.rowgroup_sum(dh1, g[q + "linear1.bias"].view(1, mlp))
         _wgrad(dh1, t1, g[q + "linear1.weight"], mlp, E, M)
         dt1 = ops.gemm(dh1, p[q + "linear1.weight"], M, E, mlp, trans_b=True, resid=ds2, res_rows=M)   # + residual branch
         ds1 = ops.layernorm_bwd(s1, st1, p[q + "norm1.weight"], dt1, g[q + "norm1.weight"], g[q + "norm1.bias"])
-        ops.rowgroup_sum(ds1, g[q + "self_attn.out_proj.bias"].view(1, E))
-        _wgrad(ds1, o, g[q + "self_attn.out_proj.weight"], E, E, M)
-        d_o = ops.gemm(ds1, p[q + "self_attn.out_proj.weight"], M, E, E, trans_b=True)
-        dqkv = ops.attention_bwd(qkv, P, d_o, B, S, E, n_heads)
+        da = ds1 if drop is None else ops.dropout(ds1, dr[1])
+        ops.rowgroup_sum(da, g[q + "self_attn.out_proj.bias"].view(1, E))
+        _wgrad(da, o, g[q + "self_attn.out_proj.weight"], E, E, M)
+        d_o = ops.gemm(da, p[q + "self_attn.out_proj.weight"], M, E, E, trans_b=True)
+        dqkv = ops.attention_bwd(qkv, P, d_o, B, S, E, n_heads, drop=dr[0])
         ops.rowgroup_sum(dqkv, g[q + "self_attn.in_proj_bias"].view(1, 3 * E))
         _wgrad(dqkv, t_in, g[q + "self_attn.in_proj_weight"], 3 * E, E, M)
         dt = ops.gemm(dqkv, p[q + "self_attn.in_proj_weight"], M, E, 3 * E, trans_b=True, resid=ds1, res_rows=M)
@@ -174,15 +191,28 @@ class CNNTransformer(_HipModule):
                                      nn.Conv2d(quarter, out_channels, kernel_size=1))
         self._finish_init()
 
-    def _check_dropout(self):
-        if self.training and self.dropout_p > 0.0:
-            raise RuntimeError("CNNTransformer (climate_amd): the HIP path implements the dropout-free function; "
-                               f"training mode with dropout={self.dropout_p} is not available -- construct the model "
-                               "with model.dropout=0 or call .eval()")
+    def _rng_state(self, device) -> Tensor:
+        """{seed, step counter} on the device (int32 x 2).  The seed is drawn from torch's global generator the first
+        time it is needed (so ``torch.manual_seed`` / ``cfg.seed`` decide it); ``reseed_dropout`` sets it explicitly."""
+        rng = self.__dict__.get("_rng")
+        if rng is None or rng.device != device:
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if rng is None else int(rng[0].item())
+            rng = torch.tensor([seed, 0], dtype=torch.int32, device=device)
+            self.__dict__["_rng"] = rng
+        return rng
+
+    def reseed_dropout(self, seed: int, counter: int = 0) -> None:
+        dev = next(self.parameters()).device
+        self.__dict__["_rng"] = torch.tensor([int(seed) & 0x7fffffff, int(counter)], dtype=torch.int32, device=dev)
 
     def _engine_forward(self, p, pk, x, save=True, head=True):
-        self._check_dropout()
-        return forward(p, x, self.n_heads, save=save, head=head)
+        drop = None
+        if self.training and self.dropout_p > 0.0:
+            rng = self._rng_state(x.device)
+            ops.rng_advance(rng)
+            # this call's snapshot: a later forward (gradient accumulation) must not change the masks of this backward
+            drop = (rng.clone(), self.dropout_p)
+        return forward(p, x, self.n_heads, save=save, head=head, drop=drop)
 
     def _engine_backward(self, p, pk, g, sv, dpred, need_dx=False, dd1=None):
         return backward(p, g, sv, self.n_heads, dpred=dpred, dd_head=dd1, need_dx=need_dx)

@@ -53,6 +53,34 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf
 // accurate variants (expf / tanhf) are used where the 1e-4 parity budget matters
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.f / (1.f + expf(-x)); }
 
+// Counter-based dropout (cnn_transformer; nn.Dropout / the attention-probability dropout of nn.MultiheadAttention,
+// reference src/cnn_transformer.py:26-33).  Nothing is stored: forward and backward REGENERATE the same decision from
+// (seed, step counter, site id, element index) with a 32-bit avalanche hash ("lowbias32").  rng = {seed, counter} lives in
+// device memory so that a replayed hipGraph draws fresh masks every step (cm_rng_advance).  The stream differs from
+// torch's Philox stream by construction -- masks are statistically, not bitwise, the reference's.
+__device__ __forceinline__ unsigned cm_hash32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+struct DropSite {
+  unsigned key, thresh;   // drop when hash(idx ^ key) < thresh
+  float scale;            // 1 / (1 - p); 0 thresh = dropout off
+};
+__device__ __forceinline__ DropSite cm_drop_site(const unsigned* rng, unsigned site, float p) {
+  DropSite d;
+  d.thresh = 0u; d.scale = 1.f; d.key = 0u;
+  if (rng != nullptr && p > 0.f) {
+    d.key = cm_hash32(rng[0] ^ cm_hash32(rng[1] * 0x9e3779b9u + site));
+    d.thresh = p >= 1.f ? 0xffffffffu : (unsigned)(p * 4294967296.0f);
+    d.scale = p >= 1.f ? 0.f : 1.f / (1.f - p);
+  }
+  return d;
+}
+// multiplier of element idx: 0 (dropped) or 1 / (1 - p)
+__device__ __forceinline__ float cm_drop_mul(const DropSite& d, unsigned idx) {
+  return (d.thresh != 0u && cm_hash32(idx ^ d.key) < d.thresh) ? 0.f : d.scale;
+}
+
 __host__ __device__ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 #define CM_CHECK_LAUNCH()                      \

@@ -30,6 +30,10 @@ struct GemmArgs {
   const float* mask;      // [M][ldm] or null: C = mask[m][n] > 0 ? C : 0   (ReLU backward through a stored output)
   long long lda, ldb, ldc, ldr, ldm;
   int M, N, K, res_rows, relu, ksplit;
+  const unsigned* rng;    // dropout (common.h) applied after bias / ReLU, before the residual; null = off
+  unsigned site;
+  float drop_p;
+  float mask_scale;       // factor on the elements the mask keeps (ReLU backward through a DROPPED activation: 1/(1-p))
 };
 
 constexpr int GBM = 128, GBN = 128, GBK = 32;
@@ -182,6 +186,7 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
   // ---- epilogue: undo the scales, bias / residual / ReLU / mask, store (or accumulate for split K) ----
   const float ia = bea <= 13u ? 0.f : __uint_as_float((bea - 13u) << 23);
   const float ib = beb <= 13u ? 0.f : __uint_as_float((beb - 13u) << 23);
+  const DropSite drop = cm_drop_site(a.rng, a.site, a.drop_p);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -199,8 +204,9 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
           continue;
         }
         if (a.relu) v = fmaxf(v, 0.f);                              // (ReLU first: relu(conv) + pos_embedding)
+        if (drop.thresh) v *= cm_drop_mul(drop, (unsigned)m * (unsigned)a.N + (unsigned)n);   // x + dropout(sublayer)
         if (a.resid) v += a.resid[(long long)(m % a.res_rows) * a.ldr + n];
-        if (a.mask && !(a.mask[(long long)m * a.ldm + n] > 0.f)) v = 0.f;
+        if (a.mask) v = a.mask[(long long)m * a.ldm + n] > 0.f ? v * a.mask_scale : 0.f;
         a.C[(long long)m * a.ldc + n] = v;
       }
     }
@@ -212,16 +218,19 @@ extern "C" {
 
 int cm_gemm_h3(const float* a, long long lda, int trans_a, const float* b, long long ldb, int trans_b, float* c,
                long long ldc, const float* bias, const float* resid, long long ldr, int res_rows, const float* mask,
-               long long ldm, int relu, int m, int n, int k, int ksplit, cm_stream stream) {
+               long long ldm, float mask_scale, int relu, const unsigned* rng, unsigned site, float drop_p, int m, int n,
+               int k, int ksplit, cm_stream stream) {
   if (m <= 0 || n <= 0 || k <= 0 || !a || !b || !c || lda <= 0 || ldb <= 0 || ldc < n) return -22;
   if (ksplit < 1) ksplit = 1;
-  if (ksplit > 1 && (resid || mask || relu)) return -22;      // split K accumulates raw sums into a zeroed C
+  if (ksplit > 1 && (resid || mask || relu || (rng && drop_p > 0.f))) return -22;   // split K accumulates raw sums
+  if (drop_p < 0.f || drop_p > 1.f || (long long)m * n > 0xffffffffLL) return -22;
   if (resid && (res_rows <= 0 || ldr < n)) return -22;
   if (mask && ldm < n) return -22;
   GemmArgs g;
   g.A = a; g.B = b; g.C = c; g.bias = bias; g.resid = resid; g.mask = mask;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.ldm = ldm;
   g.M = m; g.N = n; g.K = k; g.res_rows = res_rows > 0 ? res_rows : m; g.relu = relu;
+  g.rng = drop_p > 0.f ? rng : nullptr; g.site = site; g.drop_p = drop_p; g.mask_scale = mask_scale;
   const int nstage = cdiv(k, GBK);
   g.ksplit = ksplit > nstage ? nstage : ksplit;
   const dim3 grid(cdiv(n, GBN), cdiv(m, GBM), g.ksplit);

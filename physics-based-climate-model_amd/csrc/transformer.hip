@@ -106,7 +106,8 @@ constexpr int AKMAX = 64;    // keys per lane at most (S <= 256)
 
 template <int D>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ P,
-                                                       float* __restrict__ O, int S, int E, int H, float scale) {
+                                                       float* __restrict__ O, int S, int E, int H, float scale,
+                                                       const unsigned* __restrict__ rng, unsigned site, float drop_p) {
   extern __shared__ float sh[];              // K [S][D+1], V [S][D+1]
   float* Ks = sh;
   float* Vs = sh + (size_t)S * (D + 1);
@@ -151,15 +152,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
   float o[D];
 #pragma unroll
   for (int d = 0; d < D; ++d) o[d] = 0.f;
-  float* prow = P + (((long long)b * H + h) * S + (live ? qi : 0)) * S;
+  const long long prow_i = (((long long)b * H + h) * S + (live ? qi : 0)) * S;
+  float* prow = P + prow_i;
+  // dropout on the attention probabilities (nn.MultiheadAttention(dropout=p)): P is stored UNdropped, the mask is a
+  // function of the element index and is regenerated by the backward kernels
+  const DropSite drop = cm_drop_site(rng, site, drop_p);
 #pragma unroll
   for (int j = 0; j < AKMAX; ++j) {
     const int key = part + 4 * j;
     if (key < S) {
       const float p = sc[j] * inv;
       if (live) prow[key] = p;
+      const float pd = drop.thresh ? p * cm_drop_mul(drop, (unsigned)(prow_i + key)) : p;
 #pragma unroll
-      for (int d = 0; d < D; ++d) o[d] += p * Vs[key * (D + 1) + d];
+      for (int d = 0; d < D; ++d) o[d] += pd * Vs[key * (D + 1) + d];
     }
   }
 #pragma unroll
@@ -177,7 +183,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
                                                          const float* __restrict__ dO, float* __restrict__ dS,
-                                                         float* __restrict__ dqkv, int S, int E, int H, float scale) {
+                                                         float* __restrict__ dqkv, int S, int E, int H, float scale,
+                                                         const unsigned* __restrict__ rng, unsigned site, float drop_p) {
   extern __shared__ float sh[];
   float* Ks = sh;
   float* Vs = sh + (size_t)S * (D + 1);
@@ -197,6 +204,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
   const long long prow = (((long long)b * H + h) * S + (live ? qi : 0)) * S;
   float dp[AKMAX], pr[AKMAX];
   float dot = 0.f;
+  const DropSite drop = cm_drop_site(rng, site, drop_p);
 #pragma unroll
   for (int j = 0; j < AKMAX; ++j) {
     const int key = part + 4 * j;
@@ -205,6 +213,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
       p = P[prow + key];
 #pragma unroll
       for (int d = 0; d < D; ++d) v += go[d] * Vs[key * (D + 1) + d];
+      if (drop.thresh) v *= cm_drop_mul(drop, (unsigned)(prow + key));     // d(P) = d(dropped P) * mask / (1 - p)
     }
     dp[j] = v; pr[j] = p;
     dot += p * v;
@@ -241,7 +250,8 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
 template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
                                                           const float* __restrict__ dS, const float* __restrict__ dO,
-                                                          float* __restrict__ dqkv, int S, int E, int H) {
+                                                          float* __restrict__ dqkv, int S, int E, int H,
+                                                          const unsigned* __restrict__ rng, unsigned site, float drop_p) {
   extern __shared__ float sh[];
   float* Qs = sh;
   float* Gs = sh + (size_t)S * (D + 1);
@@ -260,8 +270,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restric
 #pragma unroll
   for (int d = 0; d < D; ++d) { dv[d] = 0.f; dk[d] = 0.f; }
   const long long pbase = ((long long)b * H + h) * S * S;
+  const DropSite drop = cm_drop_site(rng, site, drop_p);
   for (int qq = part; qq < S; qq += 4) {
-    const float p = live ? P[pbase + (long long)qq * S + key] : 0.f;
+    float p = live ? P[pbase + (long long)qq * S + key] : 0.f;
+    if (drop.thresh) p *= cm_drop_mul(drop, (unsigned)(pbase + (long long)qq * S + key));   // dV sees the DROPPED P
     const float ds = live ? dS[pbase + (long long)qq * S + key] : 0.f;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -351,6 +363,17 @@ __global__ void relu_kernel(float* __restrict__ x, long long n) {
     x[i] = fmaxf(x[i], 0.f);
 }
 
+// out = in * (0 | 1/(1-p)) by the counter-based mask of (rng, site) -- element index = flat index
+__global__ void dropout_kernel(const float* __restrict__ in, float* __restrict__ out, long long n,
+                               const unsigned* __restrict__ rng, unsigned site, float p) {
+  const DropSite drop = cm_drop_site(rng, site, p);
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * gridDim.x)
+    out[i] = in[i] * cm_drop_mul(drop, (unsigned)i);
+}
+__global__ void rng_advance_kernel(unsigned* rng) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) rng[1] += 1u;
+}
+
 // g = (y > 0) ? g : 0 in place (y = the ReLU's stored OUTPUT)
 __global__ void relu_mask_kernel(float* __restrict__ g, const float* __restrict__ y, long long n) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
@@ -424,37 +447,41 @@ static bool attn_ok(int b, int s, int e, int h) {
   return b > 0 && s > 0 && s <= 4 * AKMAX && h > 0 && e % h == 0 && (e / h == 8 || e / h == 16 || e / h == 32);
 }
 
-int cm_attention_fwd(const float* qkv, float* p, float* o, int b, int s, int e, int h, cm_stream stream) {
-  if (!attn_ok(b, s, e, h) || !qkv || !p || !o) return -22;
+int cm_attention_fwd(const float* qkv, float* p, float* o, const unsigned* rng, unsigned site, float drop_p, int b, int s,
+                     int e, int h, cm_stream stream) {
+  if (!attn_ok(b, s, e, h) || !qkv || !p || !o || drop_p < 0.f || drop_p > 1.f) return -22;
+  if ((long long)b * h * s * s > 0xffffffffLL) return -22;     // the dropout index is 32 bits
+  if (drop_p == 0.f) rng = nullptr;
   const int d = e / h;
   const size_t lds = 2 * (size_t)s * (d + 1) * sizeof(float);
   const dim3 grid(cdiv(s, AQ), h, b);
   const float scale = 1.f / sqrtf((float)d);
   hipStream_t st = (hipStream_t)stream;
-  if (d == 32) attn_fwd_kernel<32><<<grid, 256, lds, st>>>(qkv, p, o, s, e, h, scale);
-  else if (d == 16) attn_fwd_kernel<16><<<grid, 256, lds, st>>>(qkv, p, o, s, e, h, scale);
-  else attn_fwd_kernel<8><<<grid, 256, lds, st>>>(qkv, p, o, s, e, h, scale);
+  if (d == 32) attn_fwd_kernel<32><<<grid, 256, lds, st>>>(qkv, p, o, s, e, h, scale, rng, site, drop_p);
+  else if (d == 16) attn_fwd_kernel<16><<<grid, 256, lds, st>>>(qkv, p, o, s, e, h, scale, rng, site, drop_p);
+  else attn_fwd_kernel<8><<<grid, 256, lds, st>>>(qkv, p, o, s, e, h, scale, rng, site, drop_p);
   CM_CHECK_LAUNCH();
   return 0;
 }
 
-int cm_attention_bwd(const float* qkv, const float* p, const float* d_o, float* ds_scratch, float* dqkv, int b, int s,
-                     int e, int h, cm_stream stream) {
-  if (!attn_ok(b, s, e, h) || !qkv || !p || !d_o || !ds_scratch || !dqkv) return -22;
+int cm_attention_bwd(const float* qkv, const float* p, const float* d_o, float* ds_scratch, float* dqkv,
+                     const unsigned* rng, unsigned site, float drop_p, int b, int s, int e, int h, cm_stream stream) {
+  if (!attn_ok(b, s, e, h) || !qkv || !p || !d_o || !ds_scratch || !dqkv || drop_p < 0.f || drop_p > 1.f) return -22;
+  if (drop_p == 0.f) rng = nullptr;
   const int d = e / h;
   size_t lds = 2 * (size_t)s * (d + 1) * sizeof(float);
   const size_t red = 4 * 64 * (size_t)d * sizeof(float);
   const dim3 grid(cdiv(s, AQ), h, b);
   const float scale = 1.f / sqrtf((float)d);
   hipStream_t st = (hipStream_t)stream;
-  if (d == 32) attn_bwd_q_kernel<32><<<grid, 256, lds, st>>>(qkv, p, d_o, ds_scratch, dqkv, s, e, h, scale);
-  else if (d == 16) attn_bwd_q_kernel<16><<<grid, 256, lds, st>>>(qkv, p, d_o, ds_scratch, dqkv, s, e, h, scale);
-  else attn_bwd_q_kernel<8><<<grid, 256, lds, st>>>(qkv, p, d_o, ds_scratch, dqkv, s, e, h, scale);
+  if (d == 32) attn_bwd_q_kernel<32><<<grid, 256, lds, st>>>(qkv, p, d_o, ds_scratch, dqkv, s, e, h, scale, rng, site, drop_p);
+  else if (d == 16) attn_bwd_q_kernel<16><<<grid, 256, lds, st>>>(qkv, p, d_o, ds_scratch, dqkv, s, e, h, scale, rng, site, drop_p);
+  else attn_bwd_q_kernel<8><<<grid, 256, lds, st>>>(qkv, p, d_o, ds_scratch, dqkv, s, e, h, scale, rng, site, drop_p);
   CM_CHECK_LAUNCH();
   if (red > lds) lds = red;
-  if (d == 32) attn_bwd_kv_kernel<32><<<grid, 256, lds, st>>>(qkv, p, ds_scratch, d_o, dqkv, s, e, h);
-  else if (d == 16) attn_bwd_kv_kernel<16><<<grid, 256, lds, st>>>(qkv, p, ds_scratch, d_o, dqkv, s, e, h);
-  else attn_bwd_kv_kernel<8><<<grid, 256, lds, st>>>(qkv, p, ds_scratch, d_o, dqkv, s, e, h);
+  if (d == 32) attn_bwd_kv_kernel<32><<<grid, 256, lds, st>>>(qkv, p, ds_scratch, d_o, dqkv, s, e, h, rng, site, drop_p);
+  else if (d == 16) attn_bwd_kv_kernel<16><<<grid, 256, lds, st>>>(qkv, p, ds_scratch, d_o, dqkv, s, e, h, rng, site, drop_p);
+  else attn_bwd_kv_kernel<8><<<grid, 256, lds, st>>>(qkv, p, ds_scratch, d_o, dqkv, s, e, h, rng, site, drop_p);
   CM_CHECK_LAUNCH();
   return 0;
 }
@@ -487,6 +514,20 @@ int cm_transpose_batched(const float* in, float* out, int batch, int rows, int c
 int cm_relu(float* x, long long n, cm_stream stream) {
   if (n <= 0 || !x) return -22;
   relu_kernel<<<grid_for(n), 256, 0, (hipStream_t)stream>>>(x, n);
+  CM_CHECK_LAUNCH();
+  return 0;
+}
+
+int cm_dropout(const float* in, float* out, long long n, const unsigned* rng, unsigned site, float p, cm_stream stream) {
+  if (n <= 0 || n > 0xffffffffLL || !in || !out || !rng || p < 0.f || p > 1.f) return -22;
+  dropout_kernel<<<grid_for(n), 256, 0, (hipStream_t)stream>>>(in, out, n, rng, site, p);
+  CM_CHECK_LAUNCH();
+  return 0;
+}
+
+int cm_rng_advance(unsigned* rng, cm_stream stream) {
+  if (!rng) return -22;
+  rng_advance_kernel<<<1, 64, 0, (hipStream_t)stream>>>(rng);
   CM_CHECK_LAUNCH();
   return 0;
 }

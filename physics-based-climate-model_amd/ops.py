@@ -598,18 +598,28 @@ def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_dec
 
 
 # ----------------------------------------------------------------------------------------------------- cnn_transformer
+def _drop_args(drop):
+    """drop = None | (rng int32[2] device tensor, site id, p) -> (rng pointer, site, p) for the launchers."""
+    if drop is None or drop[2] <= 0.0:
+        return None, 0, 0.0
+    rng, site, p = drop
+    return _p_any(rng), int(site), float(p)
+
+
 def gemm(a, b, m, n, k, trans_a=False, trans_b=False, bias=None, resid=None, res_rows=0, mask=None, relu=False,
-         out=None, ksplit=1, lda=None, ldb=None):
+         out=None, ksplit=1, lda=None, ldb=None, drop=None, mask_scale=1.0):
     """out[m, n] = relu?(op(a) op(b) + bias) + resid (masked) on the fp16x3 GEMM kernel (cm_gemm_h3).  a / b are 2-D
     row-major tensors: a is [m, k] (or [k, m] when trans_a), b is [n, k] -- an nn.Linear weight, out = a b^T -- (or
-    [k, n] when trans_b).  ksplit > 1 ACCUMULATES into ``out`` (which the caller zeroed)."""
+    [k, n] when trans_b).  ksplit > 1 ACCUMULATES into ``out`` (which the caller zeroed).  ``drop`` = (rng, site, p):
+    counter-based dropout after bias / ReLU, before the residual; ``mask_scale`` multiplies what ``mask`` keeps."""
     if out is None:
         out = torch.empty(m, n, device=a.device, dtype=torch.float32)
     lda = a.stride(0) if lda is None else lda
     ldb = b.stride(0) if ldb is None else ldb
     check(lib.cm_gemm_h3(_p(a), lda, int(trans_a), _p(b), ldb, int(trans_b), _p(out), out.stride(0), _p(bias), _p(resid),
                          0 if resid is None else resid.stride(0), res_rows, _p(mask),
-                         0 if mask is None else mask.stride(0), int(relu), m, n, k, ksplit, _stream()), "gemm_h3")
+                         0 if mask is None else mask.stride(0), float(mask_scale), int(relu), *_drop_args(drop), m, n, k,
+                         ksplit, _stream()), "gemm_h3")
     return out
 
 
@@ -631,19 +641,32 @@ def layernorm_bwd(s, stats, gamma, dy, dgamma, dbeta):
     return ds
 
 
-def attention_fwd(qkv, b, s, e, h):
+def attention_fwd(qkv, b, s, e, h, drop=None):
     p = torch.empty(b, h, s, s, device=qkv.device, dtype=torch.float32)
     o = torch.empty(b * s, e, device=qkv.device, dtype=torch.float32)
-    check(lib.cm_attention_fwd(_p(_contig(qkv)), _p(p), _p(o), b, s, e, h, _stream()), "attention_fwd")
+    check(lib.cm_attention_fwd(_p(_contig(qkv)), _p(p), _p(o), *_drop_args(drop), b, s, e, h, _stream()), "attention_fwd")
     return p, o
 
 
-def attention_bwd(qkv, p, d_o, b, s, e, h):
+def attention_bwd(qkv, p, d_o, b, s, e, h, drop=None):
     scratch = torch.empty_like(p)
     dqkv = torch.empty_like(qkv)
-    check(lib.cm_attention_bwd(_p(qkv), _p(p), _p(_contig(d_o)), _p(scratch), _p(dqkv), b, s, e, h, _stream()),
-          "attention_bwd")
+    check(lib.cm_attention_bwd(_p(qkv), _p(p), _p(_contig(d_o)), _p(scratch), _p(dqkv), *_drop_args(drop), b, s, e, h,
+                               _stream()), "attention_bwd")
     return dqkv
+
+
+def dropout(x, drop):
+    """x * mask / (1 - p) with the counter-based mask of drop = (rng, site, p) (element index = flat index of x)."""
+    x = _contig(x)
+    out = torch.empty_like(x)
+    rng, site, p = drop
+    check(lib.cm_dropout(_p(x), _p(out), x.numel(), _p_any(rng), int(site), float(p), _stream()), "dropout")
+    return out
+
+
+def rng_advance(rng):
+    check(lib.cm_rng_advance(_p_any(rng), _stream()), "rng_advance")
 
 
 def im2col_s2(x, b, cin, h, w, ldc, tokens_in):

@@ -141,9 +141,115 @@ def test_cnn_transformer_vs_reference_fixture(ops):
             worst = max(worst, err)
             assert err < TOL, (k, err)
     print(f"cnn_transformer tiny: worst grad rel-L2 {worst:.2e}")
-    m.train()
-    with pytest.raises(RuntimeError, match="dropout"):
-        m(x)
+    m.train()                                             # dropout 0.1 now active: a different function of x
+    y_tr = m(x)
+    assert torch.isfinite(y_tr).all() and rel_l2(y_tr, g["y_eval"]) > 1e-3
+
+
+def _device_masks(ops, m, rng, B, S, E, H, mlp, depth, p):
+    """The multipliers (0 or 1/(1-p)) the kernels apply at every dropout site for the {seed, counter} snapshot ``rng``,
+    exported with the stand-alone launcher (same hash, same element indices) in the oracle's logical shapes."""
+    shapes = {0: (B, H, S, S), 1: (B, S, E), 2: (B, S, mlp), 3: (B, S, E)}
+    return {(i, k): ops.dropout(torch.ones(shp, device="cuda"), (rng, 4 * i + k, p)).cpu().double()
+            for i in range(depth) for k, shp in shapes.items()}
+
+
+def test_dropout_mask_statistics_and_streams(ops):
+    """Counter-based dropout: keep rate within 4 sigma, multiplier 1/(1-p), different masks per site / step / seed,
+    identical masks for identical (seed, counter, site) -- the property forward and backward rely on."""
+    n = 1 << 20
+    ones = torch.ones(n, device="cuda")
+    for p in (0.1, 0.5):
+        rng = torch.tensor([1234, 7], dtype=torch.int32, device="cuda")
+        a = ops.dropout(ones, (rng, 3, p))
+        kept = (a != 0)
+        assert torch.all(a[kept] == a[kept][0]) and abs(a[kept][0].item() - 1 / (1 - p)) < 1e-6
+        rate = kept.float().mean().item()
+        assert abs(rate - (1 - p)) < 4 * math.sqrt(p * (1 - p) / n), rate
+        assert torch.equal(a, ops.dropout(ones, (rng.clone(), 3, p)))
+        b = ops.dropout(ones, (rng, 4, p))                                           # another site
+        ops.rng_advance(rng)
+        assert rng.tolist() == [1234, 8]
+        c = ops.dropout(ones, (rng, 3, p))                                           # another step
+        d = ops.dropout(ones, (torch.tensor([1235, 7], dtype=torch.int32, device="cuda"), 3, p))   # another seed
+        for other in (b, c, d):
+            agree = ((a != 0) == (other != 0)).float().mean().item()
+            expect = p * p + (1 - p) * (1 - p)                                       # independent masks
+            assert abs(agree - expect) < 0.01, (agree, expect)
+        # no visible structure along the index: neighbouring elements are uncorrelated
+        k = kept.float() - (1 - p)
+        assert abs((k[:-1] * k[1:]).mean().item()) < 4 * p * (1 - p) / math.sqrt(n)
+
+
+def test_cnn_transformer_train_mode_dropout_vs_oracle_with_device_masks(ops):
+    """Training mode, dropout 0.1 (the reference's configuration): the kernels' masks are exported, imposed on the
+    float64 oracle, and loss + every gradient compared at 1e-4 -- forward and backward regenerate identical masks at all
+    four sites of every layer (attention probabilities, after attention, inside the MLP, after the MLP)."""
+    from climate_amd.cnn_transformer import CNNTransformer
+    torch.manual_seed(5)
+    B, E, depth, H, mlp, S, p = 3, 64, 2, 4, 96, 216, 0.1
+    m = CNNTransformer(5, 2, E, depth, H, mlp, dropout=p)
+    P = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.cuda().train()
+    m.reseed_dropout(99)
+    gen = torch.Generator("cpu").manual_seed(6)
+    x = torch.randn(B, 5, 48, 72, generator=gen); y = torch.randn(B, 2, 48, 72, generator=gen)
+    pred = m(x.cuda()); loss = F.mse_loss(pred, y.cuda()); loss.backward()
+    rng = m._rng.clone()                                   # the snapshot this forward used: {99, 1}
+    assert rng.tolist() == [99, 1]
+    masks = _device_masks(ops, m, rng, B, S, E, H, mlp, depth, p)
+    frac = sum((v == 0).double().mean().item() for v in masks.values()) / len(masks)
+    assert abs(frac - p) < 0.005
+    pd = {k: v.double().requires_grad_() for k, v in P.items()}
+    lo = F.mse_loss(oracle.cnn_transformer_forward(pd, x.double(), H, masks=masks), y.double()); lo.backward()
+    assert abs(loss.item() - lo.item()) < 1e-5 * lo.item()
+    named = dict(m.named_parameters())
+    worst = 0.0
+    for k in pd:
+        got, want = named[k].grad, pd[k].grad
+        if k.endswith("self_attn.in_proj_bias"):            # the key third has an identically zero true gradient
+            e3 = got.numel() // 3
+            got, want = torch.cat([got[:e3], got[2 * e3:]]), torch.cat([want[:e3], want[2 * e3:]])
+        err = rel_l2(got, want)
+        worst = max(worst, err)
+        assert err < TOL, (k, err)
+    print(f"cnn_transformer train mode (dropout {p}): worst grad rel-L2 vs float64 oracle with the device's masks {worst:.2e}")
+    # a second forward draws new masks (the counter advanced), eval() is the dropout-free function
+    pred2 = m(x.cuda())
+    assert m._rng.tolist() == [99, 2] and rel_l2(pred2, pred) > 1e-3
+    m.eval()
+    with torch.no_grad():
+        assert rel_l2(m(x.cuda()), oracle.cnn_transformer_forward(P, x, H)) < TOL
+
+
+def test_cnn_transformer_dropout_through_graphed_trainer(ops):
+    """The fused trainer replays ONE hipGraph: the device-side counter must still give every step fresh masks, and the
+    backward of a step must see the masks of its own forward (checked against the oracle with exported masks)."""
+    from climate_amd.cnn_transformer import CNNTransformer
+    from climate_amd.trainer import HotPathTrainer
+    torch.manual_seed(7)
+    B, E, depth, H, mlp, S, p = 2, 32, 1, 4, 48, 216, 0.1
+    m = CNNTransformer(5, 2, E, depth, H, mlp, dropout=p).cuda().train()
+    m.reseed_dropout(5)
+    tr = HotPathTrainer(m, lr=5e-4, use_graph=True, distributed=False)
+    gen = torch.Generator("cpu").manual_seed(8)
+    x = torch.randn(B, 5, 48, 72, generator=gen); y = torch.randn(B, 2, 48, 72, generator=gen)
+    names = [n for n, _ in m.named_parameters()]
+    for step in range(3):
+        before = {k: v.detach().cpu().double().requires_grad_() for k, v in m.state_dict().items()}
+        loss = tr.step(x.cuda(), y.cuda()).item()
+        rng = m._rng.clone()
+        masks = _device_masks(ops, m, rng, B, S, E, H, mlp, depth, p)
+        lo = F.mse_loss(oracle.cnn_transformer_forward(before, x.double(), H, masks=masks), y.double()); lo.backward()
+        assert abs(loss - lo.item()) < 1e-5 * lo.item(), (step, loss, lo.item(), rng.tolist())
+        gview = m._views(tr.grad)                          # name -> view of the flat gradient buffer (256-B aligned slots)
+        for k in names:
+            got, want = gview[k].detach().cpu().double(), before[k].grad
+            if k.endswith("self_attn.in_proj_bias"):
+                e3 = got.numel() // 3
+                got, want = torch.cat([got[:e3], got[2 * e3:]]), torch.cat([want[:e3], want[2 * e3:]])
+            assert rel_l2(got, want) < TOL, (step, k)
+    assert m._rng[1].item() >= 3                             # (warm-up passes of the capture advance it as well)
 
 
 def test_cnn_transformer_config4_width_vs_oracle(ops):
