@@ -155,6 +155,91 @@ def self_launch(args, argv):
     raise SystemExit(max(abs(rc) for rc in rcs))
 
 
+def bench_cnn_transformer(args):
+    """BASELINE.json configs[3]: cnn_transformer embed 256, depth 6, 8 heads, mlp 256, dropout 0.1 (training mode), 48x72,
+    batch 64 (unless --batch is given), one GPU: fused step through the hipGraph trainer; same JSON contract."""
+    from climate_amd.config import load_config
+    import climate_amd
+    from climate_amd.model import get_model
+    from climate_amd.profiler import KernelTimer
+    from climate_amd.trainer import HotPathTrainer
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.gpus != 1:
+        raise SystemExit("--model cnn_transformer is a single-GPU line")
+    dev = torch.device("cuda", 0)
+    B = 64 if args.batch == 32 else args.batch
+    cfg = load_config(os.path.join(climate_amd._PKG_DIR, "configs"),
+                      overrides=["model=cnn_transformer", "model.embed_dim=256", "model.depth=6", "model.n_heads=8"])
+    torch.manual_seed(cfg.seed)
+    model = get_model(cfg).to(dev).train()
+    gen = torch.Generator("cpu").manual_seed(1234)
+    x = torch.randn(B, 5, 48, 72, generator=gen).to(dev)
+    y = torch.randn(B, 2, 48, 72, generator=gen).to(dev)
+    tr = HotPathTrainer(model, lr=cfg.training.lr, weight_decay=cfg.training.weight_decay, use_graph=not args.no_graph,
+                        distributed=False)
+    sx, sy = tr.input_buffers(x.shape, y.shape)
+    sx.copy_(x); sy.copy_(y)
+    for _ in range(args.warmup):
+        tr.step(sx, sy)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tr.step(sx, sy)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kernels, roof = {}, None
+    if args.profile_steps > 0:
+        tr.use_graph = False
+        with KernelTimer() as kt:
+            for _ in range(args.profile_steps):
+                tr._fwd_bwd(sx, sy)
+                tr._adam()
+        for name, d in kt.summary().items():
+            kernels[name] = {"calls_per_step": d["calls"] / args.profile_steps,
+                             "ms_per_step": round(d["ms"] / args.profile_steps, 4)}
+            if d["flops"]:
+                kernels[name]["tflops"] = round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2)
+        gk = kt.summary().get("cm_gemm_h3")
+        if gk:
+            alg = gk["flops"] / (gk["ms"] * 1e-3) / 1e12
+            roof = {"kernel": "gemm_h3_kernel (cm_gemm_h3: linear layers, stride-2 convs as im2col GEMMs, their gradients; fp16x3)",
+                    "bound": "mfma", "achieved": round(3 * alg, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(3 * alg / PEAK_BF16_MFMA_TFLOPS, 4), "algorithmic_tflops": round(alg, 2),
+                    "traffic": None, "launches_per_step": gk["calls"] / args.profile_steps,
+                    "avg_launch_us": round(gk["ms"] * 1e3 / gk["calls"], 2)}
+    cpu = None
+    if not args.no_cpu_baseline:
+        import torch.nn.functional as F
+        import oracle
+        cores = usable_cores()
+        torch.set_num_threads(cores)
+        cb = min(B, 16)
+        P = {k: v.detach().cpu().clone().requires_grad_() for k, v in model.state_dict().items()}
+        opt = torch.optim.Adam(list(P.values()), lr=cfg.training.lr)
+        xc, yc = x[:cb].cpu(), y[:cb].cpu()
+        ts = []
+        for i in range(4):
+            t1 = time.perf_counter()
+            opt.zero_grad()
+            F.mse_loss(oracle.cnn_transformer_forward(P, xc, 8), yc).backward()
+            opt.step()
+            ts.append(time.perf_counter() - t1)
+        med = sorted(ts[1:])[1]
+        cpu = {"value": cb / med, "unit": "samples/s", "cores": cores, "kind": "port",
+               "sample": f"3 full training steps (fwd+MSE+bwd+Adam, dropout-free function) of the CPU oracle on a {cb}-sample "
+                         f"batch after 1 warm-up; median step {med * 1e3:.0f} ms"}
+    print(json.dumps({
+        "metric": "training samples/sec (cnn_transformer, 48x72 grid)", "value": round(B * args.steps / dt, 2),
+        "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"cnn_transformer embed_dim=256 depth=6 n_heads=8 mlp_dim={cfg.model.mlp_dim} dropout="
+                               f"{cfg.model.dropout} (training mode) 48x72 5->2, batch {B} (BASELINE.json configs[3]), "
+                               "fwd+MSE+bwd+Adam", "global_batch": B, "parallelism": "dp1", "hip_graph": not args.no_graph},
+        "final_loss": loss.item(), "roofline": roof, "cpu_baseline": cpu, "kernels": kernels}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,9 +255,14 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); 'gloo' allows a "
                     "multi-process rehearsal on a single GPU")
+    ap.add_argument("--model", default="unet_convlstm_attention", choices=["unet_convlstm_attention", "cnn_transformer"],
+                    help="cnn_transformer = BASELINE.json configs[3] (embed 256, depth 6, 8 heads, batch 64, dropout 0.1): a "
+                         "secondary line; the headline metric is quoted on the default model")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args, sys.argv[1:])
+    if args.model == "cnn_transformer":
+        return bench_cnn_transformer(args)
 
     from climate_amd import ddp
     from climate_amd.config import synthetic_config

@@ -53,7 +53,17 @@ def _wgrad_h3_bytes(a):
     return _wgrad_bytes(a[:8] + a[10:])
 
 
+def _gemm_flops(a):        # cm_gemm_h3(a, lda, ta, b, ldb, tb, c, ldc, bias, resid, ldr, res_rows, mask, ldm, mask_scale, relu, rng, site, p, m, n, k, ..)
+    return 2.0 * a[19] * a[20] * a[21]
+
+
+def _gemm_bytes(a):
+    m, n, k = a[19], a[20], a[21]
+    return 4.0 * (m * k + n * k + m * n)
+
+
 MODELS = {
+    "cm_gemm_h3": (_gemm_flops, _gemm_bytes),           # ALGORITHMIC flops (x3 are executed)
     "cm_conv3x3": (_conv_flops, _conv_bytes),
     "cm_conv3x3_split": (_conv_flops, _conv_bytes),     # same argument positions; ALGORITHMIC flops (x6 are executed)
     "cm_conv3x3_h3": (_conv_h3_flops, _conv_h3_bytes),  # ALGORITHMIC flops (x3 are executed)
