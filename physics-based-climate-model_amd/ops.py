@@ -641,17 +641,34 @@ def layernorm_bwd(s, stats, gamma, dy, dgamma, dbeta):
     return ds
 
 
+ATTENTION_MFMA = os.environ.get("CM_ATTENTION", "mfma") != "valu"     # CM_ATTENTION=valu: the fp32 VALU kernels everywhere
+
+
 def attention_fwd(qkv, b, s, e, h, drop=None):
-    p = torch.empty(b, h, s, s, device=qkv.device, dtype=torch.float32)
+    """softmax(Q K^T / sqrt(d)) V per (sample, head) on qkv [b*s, 3e].  Returns (saved, o): ``saved`` is what
+    attention_bwd needs -- the row statistics [b, h, s, 2] on the matrix-core path (head_dim 32, s <= 224: the
+    probabilities are recomputed), the probabilities [b, h, s, s] on the fp32 VALU path (other head sizes)."""
+    qkv = _contig(qkv)
     o = torch.empty(b * s, e, device=qkv.device, dtype=torch.float32)
-    check(lib.cm_attention_fwd(_p(_contig(qkv)), _p(p), _p(o), *_drop_args(drop), b, s, e, h, _stream()), "attention_fwd")
+    if ATTENTION_MFMA and lib.cm_attention_mfma_supported(b, s, e, h) and (drop is None or drop[2] <= 0.75):
+        stats = torch.empty(b, h, s, 2, device=qkv.device, dtype=torch.float32)
+        check(lib.cm_attention_mfma_fwd(_p(qkv), _p(stats), _p(o), *_drop_args(drop), b, s, e, h, _stream()),
+              "attention_mfma_fwd")
+        return stats, o
+    p = torch.empty(b, h, s, s, device=qkv.device, dtype=torch.float32)
+    check(lib.cm_attention_fwd(_p(qkv), _p(p), _p(o), *_drop_args(drop), b, s, e, h, _stream()), "attention_fwd")
     return p, o
 
 
-def attention_bwd(qkv, p, d_o, b, s, e, h, drop=None):
-    scratch = torch.empty_like(p)
+def attention_bwd(qkv, saved, d_o, b, s, e, h, drop=None):
     dqkv = torch.empty_like(qkv)
-    check(lib.cm_attention_bwd(_p(qkv), _p(p), _p(_contig(d_o)), _p(scratch), _p(dqkv), *_drop_args(drop), b, s, e, h,
+    if saved.shape[-1] == 2 and saved.shape[-1] != s:          # row statistics: the matrix-core path
+        dsum = torch.empty(b, h, s, device=qkv.device, dtype=torch.float32)
+        check(lib.cm_attention_mfma_bwd(_p(qkv), _p(saved), _p(_contig(d_o)), _p(dsum), _p(dqkv), *_drop_args(drop),
+                                        b, s, e, h, _stream()), "attention_mfma_bwd")
+        return dqkv
+    scratch = torch.empty_like(saved)
+    check(lib.cm_attention_bwd(_p(qkv), _p(saved), _p(_contig(d_o)), _p(scratch), _p(dqkv), *_drop_args(drop), b, s, e, h,
                                _stream()), "attention_bwd")
     return dqkv
 

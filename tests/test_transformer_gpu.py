@@ -84,9 +84,73 @@ def test_attention(ops, b, s, e, h):
     ref = (att @ v).transpose(1, 2).reshape(b * s, e)
     ref.backward(do.double())
     P, o = ops.attention_fwd(qkv.cuda(), b, s, e, h)
-    assert rel_l2(o, ref) < TOL and rel_l2(P, att) < TOL
+    assert rel_l2(o, ref) < TOL
+    if P.shape[-1] == s:                                   # fp32 VALU path: the probabilities are stored
+        assert rel_l2(P, att) < TOL
+    else:                                                  # matrix-core path (head_dim 32): row statistics only
+        sc = (q @ k.transpose(-1, -2) / math.sqrt(d)).detach()
+        assert P.shape == (b, h, s, 2)
+        assert rel_l2(P[..., 0], sc.amax(-1)) < 1e-6
+        assert rel_l2(P[..., 1], torch.exp(sc - sc.amax(-1, keepdim=True)).sum(-1)) < TOL
     dqkv = ops.attention_bwd(qkv.cuda(), P, do.cuda(), b, s, e, h)
     assert rel_l2(dqkv, qd.grad) < TOL
+    print(f"attention b{b} s{s} e{e} h{h} ({'mfma' if P.shape[-1] != s else 'valu'}): o {rel_l2(o, ref):.1e} "
+          f"dqkv {rel_l2(dqkv, qd.grad):.1e}")
+
+
+@pytest.mark.parametrize("b,s,e,h", [(2, 216, 256, 8), (1, 100, 64, 2), (2, 216, 64, 4)])
+@pytest.mark.parametrize("p", [0.1, 0.5])
+def test_attention_dropout_with_exported_mask(ops, b, s, e, h, p):
+    """Dropout on the attention probabilities, matrix-core (head_dim 32) and VALU paths: the mask the kernels regenerate
+    from (seed, counter, site, element index) is exported with cm_dropout and imposed on the float64 reference."""
+    d = e // h
+    qkv = rnd(b * s, 3 * e, seed=33); do = rnd(b * s, e, seed=34)
+    rng = torch.tensor([4321, 3], dtype=torch.int32, device="cuda")
+    drop = (rng, 17, p)
+    mask = ops.dropout(torch.ones(b, h, s, s, device="cuda"), drop).cpu().double()
+    qd = qkv.double().requires_grad_()
+    q, k, v = (z.reshape(b, s, h, d).transpose(1, 2) for z in qd.chunk(3, dim=-1))
+    att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(d), dim=-1) * mask
+    ref = (att @ v).transpose(1, 2).reshape(b * s, e)
+    ref.backward(do.double())
+    saved, o = ops.attention_fwd(qkv.cuda(), b, s, e, h, drop=drop)
+    assert rel_l2(o, ref) < TOL, rel_l2(o, ref)
+    dqkv = ops.attention_bwd(qkv.cuda(), saved, do.cuda(), b, s, e, h, drop=drop)
+    assert rel_l2(dqkv, qd.grad) < TOL, rel_l2(dqkv, qd.grad)
+
+
+def test_attention_mfma_operand_ranges(ops):
+    """Matrix-core attention with operands far outside fp16's range and heads of very different magnitude (the scales are
+    per (sample, head) powers of two from the operands' own maxima), a sharply peaked softmax and an all-zero head."""
+    b, s, e, h = 2, 216, 128, 4
+    d = e // h
+    qkv = rnd(b * s, 3 * e, seed=35).view(b, s, 3, h, d)
+    do = rnd(b * s, e, seed=36).view(b, s, h, d)
+    qkv[:, :, 0, 0] *= 30.0                                  # head 0: very peaked softmax
+    qkv[:, :, 2, 1] *= 1e8                                   # head 1: huge values
+    qkv[:, :, 1, 2] *= 1e-7                                  # head 2: tiny keys
+    qkv[0, :, :, 3] = 0.0                                    # head 3 of sample 0: all zeros (uniform attention over zeros)
+    do[:, :, 1] *= 1e-9
+    qkv = qkv.reshape(b * s, 3 * e).contiguous(); do = do.reshape(b * s, e).contiguous()
+    qd = qkv.double().requires_grad_()
+    q, k, v = (z.reshape(b, s, h, d).transpose(1, 2) for z in qd.chunk(3, dim=-1))
+    att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(d), dim=-1)
+    ref = (att @ v).transpose(1, 2).reshape(b * s, e)
+    ref.backward(do.double())
+    saved, o = ops.attention_fwd(qkv.cuda(), b, s, e, h)
+    assert saved.shape[-1] == 2 and torch.isfinite(o).all()
+    ov, rv = o.view(b, s, h, d).cpu().double(), ref.detach().view(b, s, h, d)
+    for hh in range(h):
+        assert rel_l2(ov[:, :, hh], rv[:, :, hh]) < TOL, hh
+    dqkv = ops.attention_bwd(qkv.cuda(), saved, do.cuda(), b, s, e, h)
+    gv, wv = dqkv.view(b, s, 3, h, d).cpu().double(), qd.grad.view(b, s, 3, h, d)
+    for part in range(3):
+        for hh in range(h):
+            want = wv[:, :, part, hh]
+            if want.abs().max() == 0:
+                assert gv[:, :, part, hh].abs().max() == 0
+            else:
+                assert rel_l2(gv[:, :, part, hh], want) < TOL, (part, hh, rel_l2(gv[:, :, part, hh], want))
 
 
 @pytest.mark.parametrize("b,c,h,w", [(2, 5, 48, 72), (3, 16, 8, 12), (1, 64, 24, 36)])
