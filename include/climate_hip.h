@@ -298,12 +298,12 @@ int cm_attention_bwd(const float* qkv, const float* p, const float* d_o, float* 
 /* The same attention core on the f16 matrix cores ("fp16x3", fp32-equivalent) for head_dim 32 and s <= 224 (BASELINE
  * configs[3]: "MFMA attention path"; csrc/attention_mfma.hip): nothing of size s x s is stored -- the forward keeps
  * stats [b, h, s, 2] = {row maximum of the scaled scores, row sum of exp} and the backward recomputes the probabilities
- * (dq_rowsum [b, h, s]: workspace).  drop_p <= 0.75.  cm_attention_mfma_supported: 1 when the shape qualifies.        */
+ * (o: the forward's output, dq_rowsum [b, h, s]: workspace).  drop_p <= 0.75.  cm_attention_mfma_supported: 1 when the shape qualifies.        */
 int cm_attention_mfma_supported(int b, int s, int e, int h);
 int cm_attention_mfma_fwd(const float* qkv, float* stats, float* o, const unsigned* rng, unsigned site, float drop_p,
                           int b, int s, int e, int h, cm_stream stream);
-int cm_attention_mfma_bwd(const float* qkv, const float* stats, const float* d_o, float* dq_rowsum, float* dqkv,
-                          const unsigned* rng, unsigned site, float drop_p, int b, int s, int e, int h,
+int cm_attention_mfma_bwd(const float* qkv, const float* stats, const float* o, const float* d_o, float* dq_rowsum,
+                          float* dqkv, const unsigned* rng, unsigned site, float drop_p, int b, int s, int e, int h,
                           cm_stream stream);
 /* Counter-based dropout: out[i] = in[i] * (hash(i ^ key(rng[0] = seed, rng[1] = step counter, site)) < p * 2^32 ? 0 :
  * 1 / (1 - p)).  Nothing is stored: every consumer regenerates the decision from the element index (row-major index of

@@ -145,7 +145,7 @@ def backward(p: Dict[str, Tensor], g: Dict[str, Tensor], sv, n_heads: int, dpred
         ops.rowgroup_sum(da, g[q + "self_attn.out_proj.bias"].view(1, E))
         _wgrad(da, o, g[q + "self_attn.out_proj.weight"], E, E, M)
         d_o = ops.gemm(da, p[q + "self_attn.out_proj.weight"], M, E, E, trans_b=True)
-        dqkv = ops.attention_bwd(qkv, P, d_o, B, S, E, n_heads, drop=dr[0])
+        dqkv = ops.attention_bwd(qkv, P, d_o, B, S, E, n_heads, drop=dr[0], o=o)
         ops.rowgroup_sum(dqkv, g[q + "self_attn.in_proj_bias"].view(1, 3 * E))
         _wgrad(dqkv, t_in, g[q + "self_attn.in_proj_weight"], 3 * E, E, M)
         dt = ops.gemm(dqkv, p[q + "self_attn.in_proj_weight"], M, E, 3 * E, trans_b=True, resid=ds1, res_rows=M)

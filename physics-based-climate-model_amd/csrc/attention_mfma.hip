@@ -10,7 +10,7 @@
 // fp16 split.  Nothing of size S x S is written: the forward keeps the row statistics (max, sum) and the backward
 // recomputes the probabilities from Q and K (flash-attention style), once per orientation:
 //   attn_mfma_fwd     O = softmax(Q K^T / sqrt(d)) V, stats                      workgroup = (128 queries, head, sample)
-//   attn_mfma_bwd_q   dQ = dS K, D = rowsum(P o dP)           (S^T orientation)  workgroup = (128 queries, head, sample)
+//   attn_mfma_bwd_q   dQ = dS K, D = rowsum(dO o O)           (S^T orientation)  workgroup = (128 queries, head, sample)
 //   attn_mfma_bwd_kv  dV = P_drop^T dO, dK = dS^T Q           (S orientation)    workgroup = (128 keys, head, sample)
 // with dS = P o (dP - D) / sqrt(d), dP = (dO V^T) o dropout mask.  Dropout (common.h) multiplies P after the softmax;
 // its mask is a function of the element index (b, h, q, key) and is regenerated wherever P is recomputed.
@@ -321,9 +321,21 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_q_kernel(AttnArgs a) {
   const float mrow = a.stats[2 * row], linv = 1.f / a.stats[2 * row + 1];
   const DropSite drop = cm_drop_site(a.rng, a.site, a.drop_p);
   const float is = iq * ik, ip = iv * ig;
-  // One (key tile) step: P^T and the masked dP^T of this wave's 32 queries (12 MFMAs).  Two sweeps over the key tiles --
-  // the first only for D = sum_keys P dP, the second recomputes both and forms dS -- keep one pair of tiles live
-  // instead of sixteen.
+  // D = sum_keys P_drop dP = dO . O (the forward's output already contains the dropped probabilities): 16 elements per
+  // half-wave, one exchange
+  float dsum = 0.f;
+  if (qlive) {
+    const float* orow = a.O + ((long long)b * S + qi) * E + h * AD + 16 * half;
+    const float* grow = a.dO + ((long long)b * S + qi) * E + h * AD + 16 * half;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 x = *reinterpret_cast<const float4*>(orow + 4 * i), y = *reinterpret_cast<const float4*>(grow + 4 * i);
+      dsum += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+    }
+  }
+  dsum += __shfl_xor(dsum, 32, 64);
+  if (qlive && half == 0) a.Dq[row] = dsum;
+  // One (key tile) step: P^T and the masked dP^T of this wave's 32 queries (12 MFMAs).
   auto tile = [&](int kt, f32x16& p, f32x16& dp) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { p[r] = 0.f; dp[r] = 0.f; }
@@ -347,18 +359,8 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_q_kernel(AttnArgs a) {
       dp[r] = g;
     }
   };
-  float dsum = 0.f;
-#pragma unroll 1
-  for (int kt = 0; kt < NT; ++kt) {
-    f32x16 p, dp;
-    tile(kt, p, dp);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dsum += p[r] * dp[r];
-  }
-  dsum += __shfl_xor(dsum, 32, 64);
-  if (qlive && half == 0) a.Dq[row] = dsum;
   f32x16 ds[AMAXT];
-  // sweep 2: dS^T tiles (kept in registers for the common scale), their maximum
+  // dS^T tiles (all kept in registers: they share one scale, their exact maximum)
   float dmx = 0.f;
 #pragma unroll
   for (int kt = 0; kt < AMAXT; ++kt)
@@ -420,7 +422,6 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kv_kernel(AttnArgs a) {
   au32x4* Vr = Kr + 2 * AWQ * RP;         // [2][AWQ][RP]  this workgroup's V rows        (B of dP)
   float* tab = reinterpret_cast<float*>(Vr + 2 * AWQ * RP);   // [3][QP]: row max, 1 / row sum, D
   __shared__ float red[16];
-  __shared__ float wmax[8];
   const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * AWQ;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
   const float* base = a.qkv + (long long)b * S * 3 * E + h * AD;
@@ -465,18 +466,13 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kv_kernel(AttnArgs a) {
   const DropSite drop = cm_drop_site(a.rng, a.site, a.drop_p);
   const float is = iq * ik, ip = ig * iv;
   constexpr float SP = 4096.f;
-  // the dS tiles need a common scale over the whole reduction (all query tiles): sweep 1 finds max |dS|, sweep 2 does
-  // the MFMAs (scores and dP are recomputed: 12 MFMAs per tile against 12 useful ones)
-  float dmx = 0.f;
-#pragma unroll 1
-  for (int sweep = 0; sweep < 2; ++sweep) {
-    float ids = 0.f, sds = 0.f;
-    if (sweep == 1) {
-      dmx = wave_max_nonneg(dmx);
-      if (lane == 0) wmax[wave] = dmx;
-      __syncthreads();
-      sds = pow2_scale(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])), ids);
-    }
+  // The dS tiles of the whole reduction (all query tiles) must share one scale, and their maximum is not known before the
+  // first MFMA.  As in the conv kernels: RUNNING maximum (wave uniform -- a wave owns its keys' accumulators), exact
+  // power-of-two scale from it, and when the scale shrinks the dK accumulator follows (16 multiplies).  (An a-priori
+  // bound 64 max|dO| max|V| was tried first: 2^15 above the real values with near-uniform attention, which pushed the
+  // small fp16 piece into subnormals -- 5e-4 error in a training step.)
+  unsigned be_run = 0;
+  {
     f32x16 dv, dk;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dv[r] = 0.f; dk[r] = 0.f; }
@@ -506,9 +502,23 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kv_kernel(AttnArgs a) {
         const float v = p * (dp - tab[2 * QP + qi]);      // (Q^T below already carries the 1 / sqrt(d))
         pd[r] = p * m;
         c[r] = v;
-        dmx = fmaxf(dmx, fabsf(v));
       }
-      if (sweep == 1) {
+      {
+        float tm = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tm = fmaxf(tm, fabsf(c[r]));
+        const unsigned be_t = (__float_as_uint(wave_max_nonneg(tm)) >> 23) & 0xffu;
+        if (be_t > be_run) {                                   // (wave uniform) the scale 2^(140 - max(be, 13)) shrinks
+          const unsigned bn = max(be_t, 13u), bo = max(be_run, 13u);
+          if (be_run != 0u && bn > bo) {
+            const unsigned d = bn - bo;
+            const float f = d > 126u ? 0.f : __uint_as_float((127u - d) << 23);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dk[r] *= f;
+          }
+          be_run = be_t;
+        }
+        const float sds = __uint_as_float((267u - max(be_run, 13u)) << 23);
         au32x4 p0[2], p1[2], s0[2], s1[2];
         acc_to_b(pd, SP, p0, p1);
         acc_to_b(c, sds, s0, s1);
@@ -525,7 +535,8 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kv_kernel(AttnArgs a) {
         }
       }
     }
-    if (sweep == 1 && klive) {
+    if (klive) {
+      const float ids = be_run <= 13u ? 0.f : __uint_as_float((be_run - 13u) << 23);   // 2^(be - 140)
       const float iov = ig * (1.f / SP), iok = iq * ids;
       float* vp = a.dqkv + ((long long)b * S + key) * 3 * E + 2 * E + h * AD;
       float* kp = a.dqkv + ((long long)b * S + key) * 3 * E + E + h * AD;
@@ -572,12 +583,14 @@ int cm_attention_mfma_fwd(const float* qkv, float* stats, float* o, const unsign
   return 0;
 }
 
-int cm_attention_mfma_bwd(const float* qkv, const float* stats, const float* d_o, float* dq_rowsum, float* dqkv,
-                          const unsigned* rng, unsigned site, float drop_p, int b, int s, int e, int h,
+int cm_attention_mfma_bwd(const float* qkv, const float* stats, const float* o, const float* d_o, float* dq_rowsum,
+                          float* dqkv, const unsigned* rng, unsigned site, float drop_p, int b, int s, int e, int h,
                           cm_stream stream) {
-  if (!mfma_ok(b, s, e, h) || !qkv || !stats || !d_o || !dq_rowsum || !dqkv || drop_p < 0.f || drop_p > 0.75f) return -22;
+  if (!mfma_ok(b, s, e, h) || !qkv || !stats || !o || !d_o || !dq_rowsum || !dqkv || drop_p < 0.f || drop_p > 0.75f)
+    return -22;
   AttnArgs a{};
-  a.qkv = qkv; a.stats = const_cast<float*>(stats); a.dO = d_o; a.Dq = dq_rowsum; a.dqkv = dqkv;
+  a.qkv = qkv; a.stats = const_cast<float*>(stats); a.O = const_cast<float*>(o); a.dO = d_o; a.Dq = dq_rowsum;
+  a.dqkv = dqkv;
   a.S = s; a.E = e; a.H = h; a.NT = cdiv(s, 32);
   a.scale = 1.f / sqrtf((float)AD);
   a.rng = drop_p > 0.f ? rng : nullptr; a.site = site; a.drop_p = drop_p;

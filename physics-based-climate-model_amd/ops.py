@@ -650,7 +650,7 @@ def attention_fwd(qkv, b, s, e, h, drop=None):
     probabilities are recomputed), the probabilities [b, h, s, s] on the fp32 VALU path (other head sizes)."""
     qkv = _contig(qkv)
     o = torch.empty(b * s, e, device=qkv.device, dtype=torch.float32)
-    if ATTENTION_MFMA and lib.cm_attention_mfma_supported(b, s, e, h) and (drop is None or drop[2] <= 0.75):
+    if ATTENTION_MFMA and e % h == 0 and e // h == 32 and s <= 224 and (drop is None or drop[2] <= 0.75):
         stats = torch.empty(b, h, s, 2, device=qkv.device, dtype=torch.float32)
         check(lib.cm_attention_mfma_fwd(_p(qkv), _p(stats), _p(o), *_drop_args(drop), b, s, e, h, _stream()),
               "attention_mfma_fwd")
@@ -660,12 +660,15 @@ def attention_fwd(qkv, b, s, e, h, drop=None):
     return p, o
 
 
-def attention_bwd(qkv, saved, d_o, b, s, e, h, drop=None):
+def attention_bwd(qkv, saved, d_o, b, s, e, h, drop=None, o=None):
+    """``o``: the forward's output (needed on the matrix-core path: rowsum(dO o O) replaces a sweep over the keys)."""
     dqkv = torch.empty_like(qkv)
     if saved.shape[-1] == 2 and saved.shape[-1] != s:          # row statistics: the matrix-core path
+        if o is None:
+            raise RuntimeError("attention_bwd on the matrix-core path needs the forward's output `o`")
         dsum = torch.empty(b, h, s, device=qkv.device, dtype=torch.float32)
-        check(lib.cm_attention_mfma_bwd(_p(qkv), _p(saved), _p(_contig(d_o)), _p(dsum), _p(dqkv), *_drop_args(drop),
-                                        b, s, e, h, _stream()), "attention_mfma_bwd")
+        check(lib.cm_attention_mfma_bwd(_p(qkv), _p(saved), _p(_contig(o)), _p(_contig(d_o)), _p(dsum), _p(dqkv),
+                                        *_drop_args(drop), b, s, e, h, _stream()), "attention_mfma_bwd")
         return dqkv
     scratch = torch.empty_like(saved)
     check(lib.cm_attention_bwd(_p(qkv), _p(saved), _p(_contig(d_o)), _p(scratch), _p(dqkv), *_drop_args(drop), b, s, e, h,

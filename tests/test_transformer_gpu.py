@@ -92,7 +92,7 @@ def test_attention(ops, b, s, e, h):
         assert P.shape == (b, h, s, 2)
         assert rel_l2(P[..., 0], sc.amax(-1)) < 1e-6
         assert rel_l2(P[..., 1], torch.exp(sc - sc.amax(-1, keepdim=True)).sum(-1)) < TOL
-    dqkv = ops.attention_bwd(qkv.cuda(), P, do.cuda(), b, s, e, h)
+    dqkv = ops.attention_bwd(qkv.cuda(), P, do.cuda(), b, s, e, h, o=o)
     assert rel_l2(dqkv, qd.grad) < TOL
     print(f"attention b{b} s{s} e{e} h{h} ({'mfma' if P.shape[-1] != s else 'valu'}): o {rel_l2(o, ref):.1e} "
           f"dqkv {rel_l2(dqkv, qd.grad):.1e}")
@@ -115,7 +115,7 @@ def test_attention_dropout_with_exported_mask(ops, b, s, e, h, p):
     ref.backward(do.double())
     saved, o = ops.attention_fwd(qkv.cuda(), b, s, e, h, drop=drop)
     assert rel_l2(o, ref) < TOL, rel_l2(o, ref)
-    dqkv = ops.attention_bwd(qkv.cuda(), saved, do.cuda(), b, s, e, h, drop=drop)
+    dqkv = ops.attention_bwd(qkv.cuda(), saved, do.cuda(), b, s, e, h, drop=drop, o=o)
     assert rel_l2(dqkv, qd.grad) < TOL, rel_l2(dqkv, qd.grad)
 
 
@@ -142,7 +142,7 @@ def test_attention_mfma_operand_ranges(ops):
     ov, rv = o.view(b, s, h, d).cpu().double(), ref.detach().view(b, s, h, d)
     for hh in range(h):
         assert rel_l2(ov[:, :, hh], rv[:, :, hh]) < TOL, hh
-    dqkv = ops.attention_bwd(qkv.cuda(), saved, do.cuda(), b, s, e, h)
+    dqkv = ops.attention_bwd(qkv.cuda(), saved, do.cuda(), b, s, e, h, o=o)
     gv, wv = dqkv.view(b, s, 3, h, d).cpu().double(), qd.grad.view(b, s, 3, h, d)
     for part in range(3):
         for hh in range(h):
