@@ -105,7 +105,10 @@ def _add_pos(t0: Tensor, pos: Tensor, S: int) -> Tensor:
 
 def _wgrad(dy: Tensor, x: Tensor, dw: Tensor, n_out: int, k_in: int, tokens: int):
     """dw [n_out, k_in] += dy^T x  (dy [tokens, n_out], x [tokens, >= k_in]): split-K GEMM over the tokens."""
-    ks = max(1, min(64, tokens // 256))
+    # reduction split: enough workgroups to fill the chip (~384 of 128 x 128 tiles), at least 256 tokens each
+    # (tools/gemm_bench.py: 768 x 256 is fastest at 32 splits, 256 x 256 at 54)
+    tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)
+    ks = max(1, min(64, tokens // 256, max(8, 384 // tiles)))
     ops.gemm(dy, x, n_out, k_in, tokens, trans_a=True, trans_b=True, out=dw.view(n_out, k_in), ksplit=ks)
 
 
