@@ -483,6 +483,12 @@ static inline int gn_reg_slots(int cpg, int hw) {
 
 }  // namespace
 
+// largest group (in 1024-element register slots) the register-resident backward takes; CM_GN_BWD_REG overrides (0: never)
+static int gn_bwd_reg_max() {
+  static const int v = getenv("CM_GN_BWD_REG") ? atoi(getenv("CM_GN_BWD_REG")) : 14;
+  return v;
+}
+
 extern "C" {
 
 int cm_gn_silu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, float* pooled,
@@ -518,7 +524,7 @@ int cm_gn_silu_bwd(const float* x, const float* gamma, const float* beta, const 
   const bool narrow = (vec ? hw / 4 : hw) <= 64 && (c / groups) >= 8;
   hipStream_t st = (hipStream_t)stream;
   const int slots = gn_reg_slots(c / groups, hw);
-  if (vec && slots > 0 && slots <= 14 && !narrow) {
+  if (vec && slots > 0 && slots <= gn_bwd_reg_max() && !narrow) {
     if (slots <= 7)
       gn_silu_bwd_reg_kernel<0, 7><<<n * groups, GN_THREADS, 0, st>>>(x, gamma, beta, stats, dA, st_dA, gb, dx, dgamma, dbeta, c, hw, groups);
     else
@@ -561,7 +567,7 @@ int cm_gn_silu_bwd_gated(const float* x, const float* gamma, const float* beta, 
   const bool narrow = (vec ? hw / 4 : hw) <= 64 && (c / groups) >= 8;
   hipStream_t st = (hipStream_t)stream;
   const int slots = gn_reg_slots(c / groups, hw);
-  if (vec && slots > 0 && slots <= 14 && !narrow) {
+  if (vec && slots > 0 && slots <= gn_bwd_reg_max() && !narrow) {
     if (slots <= 7)
       gn_silu_bwd_reg_kernel<1, 7><<<n * groups, GN_THREADS, 0, st>>>(x, gamma, beta, stats, nullptr, 0, gb, dx, dgamma, dbeta, c, hw, groups);
     else
