@@ -354,8 +354,10 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_reg_kernel(const float
   }
 }
 
-template <int MODE, int MAXQ>
-__global__ __launch_bounds__(GN_THREADS, (MAXQ > 7 && MODE == 0) ? 3 : 1) void gn_silu_bwd_reg_kernel(const float* __restrict__ x,
+// NT threads: 256, or 512 for the largest groups -- the same group in half as many registers per thread, so that two
+// 8-wave workgroups (4 waves per SIMD instead of 2) hide the latency of the transcendental-heavy middle phase.
+template <int MODE, int MAXQ, int NT = GN_THREADS>
+__global__ __launch_bounds__(NT, (MAXQ > 7 && MODE == 0) ? 3 : 1) void gn_silu_bwd_reg_kernel(const float* __restrict__ x,
                                                                        const float* __restrict__ gamma,
                                                                        const float* __restrict__ beta,
                                                                        const float* __restrict__ stats,
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(GN_THREADS, (MAXQ > 7 && MODE == 0) ? 3 : 1) void g
   const int n = blockIdx.x / G, g = blockIdx.x % G;
   const int cpg = C / G;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int NW = GN_THREADS / 64;
+  constexpr int NW = NT / 64;
   const int HWV = HW / 4, RPC = (HWV + 63) / 64, rows = cpg * RPC;
   const float mean = stats[2 * blockIdx.x], rstd = stats[2 * blockIdx.x + 1];
   const float inv_hw = 1.f / (float)HW, inv_c = 1.f / (float)C;
@@ -489,6 +491,12 @@ static int gn_bwd_reg_max() {
   return v;
 }
 
+// 512-thread form of the register-resident backward for groups of 8..14 slots (CM_GN_BWD_WIDE=0: the 256-thread form)
+static bool gn_bwd_wide() {
+  static const bool v = !(getenv("CM_GN_BWD_WIDE") && atoi(getenv("CM_GN_BWD_WIDE")) == 0);
+  return v;
+}
+
 extern "C" {
 
 int cm_gn_silu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, float* pooled,
@@ -527,6 +535,8 @@ int cm_gn_silu_bwd(const float* x, const float* gamma, const float* beta, const 
   if (vec && slots > 0 && slots <= gn_bwd_reg_max() && !narrow) {
     if (slots <= 7)
       gn_silu_bwd_reg_kernel<0, 7><<<n * groups, GN_THREADS, 0, st>>>(x, gamma, beta, stats, dA, st_dA, gb, dx, dgamma, dbeta, c, hw, groups);
+    else if (gn_bwd_wide())
+      gn_silu_bwd_reg_kernel<0, 7, 512><<<n * groups, 512, 0, st>>>(x, gamma, beta, stats, dA, st_dA, gb, dx, dgamma, dbeta, c, hw, groups);
     else
       gn_silu_bwd_reg_kernel<0, 14><<<n * groups, GN_THREADS, 0, st>>>(x, gamma, beta, stats, dA, st_dA, gb, dx, dgamma, dbeta, c, hw, groups);
     CM_CHECK_LAUNCH();
@@ -570,6 +580,8 @@ int cm_gn_silu_bwd_gated(const float* x, const float* gamma, const float* beta, 
   if (vec && slots > 0 && slots <= gn_bwd_reg_max() && !narrow) {
     if (slots <= 7)
       gn_silu_bwd_reg_kernel<1, 7><<<n * groups, GN_THREADS, 0, st>>>(x, gamma, beta, stats, nullptr, 0, gb, dx, dgamma, dbeta, c, hw, groups);
+    else if (gn_bwd_wide())
+      gn_silu_bwd_reg_kernel<1, 7, 512><<<n * groups, 512, 0, st>>>(x, gamma, beta, stats, nullptr, 0, gb, dx, dgamma, dbeta, c, hw, groups);
     else
       gn_silu_bwd_reg_kernel<1, 14><<<n * groups, GN_THREADS, 0, st>>>(x, gamma, beta, stats, nullptr, 0, gb, dx, dgamma, dbeta, c, hw, groups);
     CM_CHECK_LAUNCH();

@@ -16,11 +16,12 @@ struct SeWgradArgs {
 };
 
 __device__ __forceinline__ void se_wgrad_chunk(const SeWgradArgs& a, int chunk, float (*part)[33]) {
-  const int wl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int wl = threadIdx.x & 31, sl = threadIdx.x >> 5;      // the first 256 threads work (callers may have 512)
+  const bool act = threadIdx.x < 256;
   const int i = chunk * 32 + wl;
   const int CCr = a.C * a.Cr, total = 2 * CCr;
   float acc = 0.f;
-  if (i < total) {
+  if (act && i < total) {
     if (i < CCr) {  // dW2[c][r]
       const int c = i / a.Cr, r = i % a.Cr;
       for (int n = sl; n < a.N; n += 8) acc += a.dsig[(long long)n * a.C + c] * fmaxf(a.z[(long long)n * a.Cr + r], 0.f);
@@ -30,7 +31,7 @@ __device__ __forceinline__ void se_wgrad_chunk(const SeWgradArgs& a, int chunk, 
       for (int n = sl; n < a.N; n += 8) acc += a.dz[(long long)n * a.Cr + r] * a.pooled[(long long)n * a.C + c];
     }
   }
-  part[sl][wl] = acc;
+  if (act) part[sl][wl] = acc;
   __syncthreads();
   if (sl == 0 && i < total) {
     float t = 0.f;
