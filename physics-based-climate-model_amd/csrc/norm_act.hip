@@ -279,8 +279,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_kernel(const float* __
 // them in registers between the reduction pass and the apply pass, so every tensor is read from HBM exactly once.
 //   forward : read x, write y                      (2 passes instead of 3)
 //   backward: read x, upstream; write dx           (3 / 4 passes instead of 6 / 7)
-template <int MAXQ>
-__global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_reg_kernel(const float* __restrict__ x,
+template <int MAXQ, int NT = GN_THREADS>
+__global__ __launch_bounds__(NT) void gn_silu_fwd_reg_kernel(const float* __restrict__ x,
                                                                        const float* __restrict__ gamma,
                                                                        const float* __restrict__ beta,
                                                                        float* __restrict__ y, float* __restrict__ stats,
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_reg_kernel(const float
   const int n = blockIdx.x / G, g = blockIdx.x % G;
   const int cpg = C / G;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int NW = GN_THREADS / 64;
+  constexpr int NW = NT / 64;
   const int HWV = HW / 4, RPC = (HWV + 63) / 64, rows = cpg * RPC;
   const long long base = ((long long)n * C + (long long)g * cpg) * HW;
   const float4* xg = reinterpret_cast<const float4*>(x + base);
@@ -511,7 +511,7 @@ int cm_gn_silu_fwd(const float* x, const float* gamma, const float* beta, float*
     if (slots <= 7)
       gn_silu_fwd_reg_kernel<7><<<n * groups, GN_THREADS, 0, st>>>(x, gamma, beta, y, stats, pooled, c, hw, groups, eps);
     else
-      gn_silu_fwd_reg_kernel<14><<<n * groups, GN_THREADS, 0, st>>>(x, gamma, beta, y, stats, pooled, c, hw, groups, eps);
+      gn_silu_fwd_reg_kernel<7, 512><<<n * groups, 512, 0, st>>>(x, gamma, beta, y, stats, pooled, c, hw, groups, eps);
     CM_CHECK_LAUNCH();
     return 0;
   }

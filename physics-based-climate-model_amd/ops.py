@@ -298,6 +298,7 @@ _cn = os.environ.get("CM_CONV_NUMERICS", "fp16x3")
 _WG_NUM = os.environ.get("CM_WGRAD_NUMERICS", _cn if _cn in ("fp16x3", "bf16x6", "fp32") else "bf16x6")
 if _WG_NUM not in ("fp16x3", "bf16x6", "fp32"):
     raise RuntimeError(f"CM_WGRAD_NUMERICS={_WG_NUM!r}: expected fp16x3, bf16x6 or fp32")
+WGRAD_ROUNDS = tuple(int(v) for v in os.environ.get("CM_WGRAD_ROUNDS", "2,4,8").split(","))   # grid sizes the tuner tries
 WGRAD_BF16X6 = _WG_NUM == "bf16x6"
 WGRAD_H3 = _WG_NUM == "fp16x3"
 
@@ -356,7 +357,7 @@ def wgrad3x3(x0, dy, g, c_off=0, x1=None, config=-1, be_x=None, be_y=None):
         cands = [c + (u << 8) for c in range(lib.cm_wgrad3x3_num_configs()) for u in (2, 3, 4, 6, 8)]
         if (WGRAD_BF16X6 or WGRAD_H3) and (c1 == 0 or c0 % 32 == 0):
             base = H3_BASE if WGRAD_H3 else SPLIT_BASE
-            cands = cands + [base + c + (u << 8) for c in range(lib.cm_wgrad3x3_split_num_configs()) for u in (2, 4, 8)]
+            cands = cands + [base + c + (u << 8) for c in range(lib.cm_wgrad3x3_split_num_configs()) for u in WGRAD_ROUNDS]
         if c1 == 0 and c0 * 9 <= 64 and w % 4 == 0 and w <= 320 and dy.stride(0) % 4 == 0:
             cands.append(SMALLC_CFG)
         config = _pick(("wgrad3x3", n, h, w, c0, c1, cout, _WG_NUM), cands, launch, -1)
