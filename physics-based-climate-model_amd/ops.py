@@ -304,8 +304,9 @@ WGRAD_H3 = _WG_NUM == "fp16x3"
 
 
 def _wgrad_call(x0, dy, g, c_off, x1, config, be_x=None, be_y=None):
-    """One launch of a weight-gradient family: ids >= SPLIT_BASE select the bf16x6 kernel (cm_wgrad3x3_split),
-    SMALLC_CFG the first-layer kernel (cm_wgrad3x3_smallc)."""
+    """One launch of a weight-gradient family: ids >= H3_BASE select the fp16x3 kernel (cm_wgrad3x3_h3, needs the
+    per-sample exponent tables), ids >= SPLIT_BASE the bf16x6 kernel (cm_wgrad3x3_split), SMALLC_CFG the first-layer
+    kernel (cm_wgrad3x3_smallc)."""
     n, c0, h, w = x0.shape
     c1 = 0 if x1 is None else x1.shape[1]
     cout, ctot = g.shape[0], g.shape[2]
@@ -331,8 +332,8 @@ def wgrad3x3(x0, dy, g, c_off=0, x1=None, config=-1, be_x=None, be_y=None):
     ``be_x`` / ``be_y`` (SampleExponents, optional): per-sample magnitudes of cat(x0, x1) / dy for the fp16x3 kernel,
     normally published by the conv launches that read the same tensors; measured here (one launch each) when missing.
 
-    With config < 0 the autotuner times the fp32-MFMA and (unless CM_WGRAD_BF16X6=0) the bf16x6 configurations on this
-    call signature and keeps the fastest."""
+    With config < 0 the autotuner times the fp32-MFMA configurations and those of the split-operand family that
+    CM_WGRAD_NUMERICS selects (fp16x3 by default) on this call signature and keeps the fastest."""
     n, c0, h, w = x0.shape
     c1 = 0 if x1 is None else x1.shape[1]
     cout = g.shape[0]
