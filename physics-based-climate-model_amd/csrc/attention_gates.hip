@@ -7,6 +7,7 @@
 //
 // Backward facts pinned by the golden fixtures: amax splits its gradient EQUALLY among tied channels (so the tie
 // count map `cnt` is built from the bit-exact product a2*s), mean_c spreads 1/C.
+#include <stdlib.h>
 #include "common.h"
 #include "se_wgrad.h"
 #include "../../include/climate_hip.h"
@@ -626,7 +627,11 @@ int cm_spatial_apply(const float* a2, const float* s, const float* map, const fl
     if (!al) return -22;
     vec = (w % 4 == 0) ? 4 : 2;                     // row pairs: vectors must not straddle rows
   }
-  const int xb = w >= 64 ? 4 : (w >= 32 ? 2 : 1);   // gate phase: ~150 busy threads per band at every level
+  // x blocking of the gate phase: 1.  The blocked forms (4 for W >= 64, 2 for W >= 32: ~150 busy threads per band at
+  // every level) cost 220-250 VGPRs = 2 waves per SIMD, and the streaming phase that follows is what the kernel's time
+  // is made of: 182 -> 162 us per step with 4 waves per SIMD (CM_APPLY_XB=4|2 selects the blocked forms).
+  static const int xb_force = getenv("CM_APPLY_XB") ? atoi(getenv("CM_APPLY_XB")) : 0;
+  const int xb = (xb_force == 4 || xb_force == 2) ? xb_force : 1;
 #define CM_APPLY(V, X)                                                                                               \
   if (vec == V && xb == X) {                                                                                         \
     if (pooled && V > 1)                                                                                             \
