@@ -69,6 +69,7 @@ class Decisions:
         self.delta = delta
         self.amax: Dict[tuple, Tensor] = {}
         self.pool: Dict[tuple, Tensor] = {}
+        self.relu: Dict[object, Tensor] = {}      # site -> bool mask "this unit is active" (cnn_transformer's ReLUs)
         self.violations = 0
         self.differing = 0
         self.sites = 0
@@ -112,6 +113,36 @@ class _MaxPoolImposed(torch.autograd.Function):
         win.scatter_(-1, idx.unsqueeze(-1), g.unsqueeze(-1))
         dx = win.view(n, c, h // 2, w // 2, 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, c, h, w)
         return dx, None
+
+
+class _ReluImposed(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mask):
+        ctx.save_for_backward(mask)
+        return x.clamp_min(0)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return g * mask.to(g.dtype), None
+
+
+def _relu(x: Tensor, dec: "Optional[Decisions]", site) -> Tensor:
+    """ReLU whose BACKWARD uses another evaluation's on/off decisions (``dec.relu[site]``).  One flipped unit of N moves
+    a gradient tensor by ~1/sqrt(N) in relative L2 (1.2e-3 at N = 663 552: measured at config-4 widths, where a
+    decoder pre-activation of 1e-8 sat on the kink after two Adam steps), so a 1e-4 comparison has to agree on the
+    units first.  An imposed decision is accepted only where the oracle's own pre-activation is within
+    ``delta * rms(x)`` of zero."""
+    if dec is None or site not in dec.relu:
+        return F.relu(x)
+    mask = dec.relu[site]
+    with torch.no_grad():
+        differ = mask != (x > 0)
+        tol = dec.delta * x.pow(2).mean().sqrt()
+        dec.violations += dec._note("relu", site, torch.where(differ, x.abs(), torch.zeros_like(x)), tol)
+        dec.differing += int(differ.sum())
+        dec.sites += mask.numel()
+    return _ReluImposed.apply(x, mask)
 
 
 def _amax_c(x: Tensor, dec: "Optional[Decisions]", site) -> Tensor:
@@ -358,18 +389,21 @@ def closed_form_params(in_ch: int, out_ch: int, base: int, dtype=torch.float32, 
 
 
 # ----------------------------------------------------------------------------- cnn_transformer (BASELINE config 4)
-def cnn_transformer_forward(p: Params, x: Tensor, n_heads: int, masks=None) -> Tensor:
+def cnn_transformer_forward(p: Params, x: Tensor, n_heads: int, masks=None, decisions: "Optional[Decisions]" = None) -> Tensor:
     """CNNTransformer.forward (src/cnn_transformer.py:44-54), dropout OFF (eval mode / p = 0) unless ``masks`` is given:
     masks[(layer, k)] = the multiplier tensor (0 or 1 / (1 - p)) of dropout site k of that layer -- 0: attention
     probabilities [B, H, S, S] (nn.MultiheadAttention(dropout)), 1: after the attention block [B, S, E], 2: inside the
     MLP after the ReLU [B, S, mlp], 3: after the MLP [B, S, E] (nn.TransformerEncoderLayer._sa_block / _ff_block) --
-    so that a test can impose another implementation's masks.  Spelled out with
+    so that a test can impose another implementation's masks; ``decisions.relu`` (sites "encoder.0", "encoder.2",
+    ("mlp", layer), "decoder.0", "decoder.2") imposes another evaluation's ReLU on/off decisions on the backward
+    (see _relu).  Spelled out with
     functional ops: two stride-2 3x3 convs + ReLU -> 216 tokens + learned positional embedding -> ``depth`` post-norm
     nn.TransformerEncoderLayer (batch_first, ReLU MLP, eps 1e-5) -> two 2x2 stride-2 transposed convs + ReLU -> 1x1.
     Parameter names are the reference's state_dict keys."""
     b = x.shape[0]
-    y = F.relu(F.conv2d(x, p["encoder.0.weight"], p["encoder.0.bias"], stride=2, padding=1))
-    y = F.relu(F.conv2d(y, p["encoder.2.weight"], p["encoder.2.bias"], stride=2, padding=1))
+    dec = decisions
+    y = _relu(F.conv2d(x, p["encoder.0.weight"], p["encoder.0.bias"], stride=2, padding=1), dec, "encoder.0")
+    y = _relu(F.conv2d(y, p["encoder.2.weight"], p["encoder.2.bias"], stride=2, padding=1), dec, "encoder.2")
     e, hh, ww = y.shape[1], y.shape[2], y.shape[3]
     t = y.flatten(2).transpose(1, 2) + p["pos_embedding"]                      # [B, S, E]
     depth = 1 + max(int(k.split(".")[2]) for k in p if k.startswith("transformer.layers."))
@@ -387,7 +421,7 @@ def cnn_transformer_forward(p: Params, x: Tensor, n_heads: int, masks=None) -> T
         if mk(1) is not None:
             o = o * mk(1)
         t = F.layer_norm(t + o, (e,), p[q + "norm1.weight"], p[q + "norm1.bias"], 1e-5)
-        hdn = F.relu(F.linear(t, p[q + "linear1.weight"], p[q + "linear1.bias"]))
+        hdn = _relu(F.linear(t, p[q + "linear1.weight"], p[q + "linear1.bias"]), dec, ("mlp", i))
         if mk(2) is not None:
             hdn = hdn * mk(2)
         m = F.linear(hdn, p[q + "linear2.weight"], p[q + "linear2.bias"])
@@ -395,6 +429,6 @@ def cnn_transformer_forward(p: Params, x: Tensor, n_heads: int, masks=None) -> T
             m = m * mk(3)
         t = F.layer_norm(t + m, (e,), p[q + "norm2.weight"], p[q + "norm2.bias"], 1e-5)
     y = t.transpose(1, 2).reshape(b, e, hh, ww)
-    y = F.relu(F.conv_transpose2d(y, p["decoder.0.weight"], p["decoder.0.bias"], stride=2))
-    y = F.relu(F.conv_transpose2d(y, p["decoder.2.weight"], p["decoder.2.bias"], stride=2))
+    y = _relu(F.conv_transpose2d(y, p["decoder.0.weight"], p["decoder.0.bias"], stride=2), dec, "decoder.0")
+    y = _relu(F.conv_transpose2d(y, p["decoder.2.weight"], p["decoder.2.bias"], stride=2), dec, "decoder.2")
     return F.conv2d(y, p["decoder.4.weight"], p["decoder.4.bias"])

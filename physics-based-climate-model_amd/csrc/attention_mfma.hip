@@ -37,8 +37,15 @@ __device__ __forceinline__ int rrec(int row, int oct) { return row * RP + (oct ^
 
 __device__ __forceinline__ float block_max3(float v, float* red, int slot) {
   v = wave_max_nonneg(v);
-  if ((threadIdx.x & 63) == 0) red[slot * 4 + (threadIdx.x >> 6)] = v;
+  if ((threadIdx.x & 63) == 0) red[slot * 8 + (threadIdx.x >> 6)] = v;      // (up to 8 waves per workgroup)
   return v;
+}
+template <int NW = 4>
+__device__ __forceinline__ float red_max(const float* red, int slot) {
+  float m = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) m = fmaxf(m, red[slot * 8 + w]);
+  return m;
 }
 
 // scale 2^(140 - be) puts a maximum with biased exponent be into [2^13, 2^14); returns the scale, *inv its inverse
@@ -53,9 +60,10 @@ __device__ __forceinline__ float pow2_scale(float mx, float& inv) {
 // Stage a [rows x 32] fp32 operand (row r at src + r * ld) as fp16 pieces: row-major records dst[piece][row][oct] (pitch
 // RP) and / or transposed records dstT[piece][d][row octet] (pitch tp).  rows beyond `valid` are zero.  `pre` multiplies
 // before the power-of-two scale `sc`.
+template <int NT = 256>
 __device__ __forceinline__ void stage_rows(const float* __restrict__ src, long long ld, int valid, int rows, float pre,
                                            float sc, au32x4* dst, int dst_rows, au32x4* dstT, int tp) {
-  for (int it = threadIdx.x; it < rows * 4; it += 256) {
+  for (int it = threadIdx.x; it < rows * 4; it += NT) {
     const int r = it >> 2, oct = it & 3;
     float v[8];
     if (r < valid) {
@@ -94,9 +102,10 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ src, long l
 }
 
 // max |x| of a [rows x 32] operand (for the scale), one thread-local partial
+template <int NT = 256>
 __device__ __forceinline__ float rows_absmax(const float* __restrict__ src, long long ld, int valid) {
   float m = 0.f;
-  for (int it = threadIdx.x; it < valid * 8; it += 256) {
+  for (int it = threadIdx.x; it < valid * 8; it += NT) {
     const float4 a = *reinterpret_cast<const float4*>(src + (long long)(it >> 3) * ld + (it & 7) * 4);
     m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
   }
@@ -158,7 +167,7 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(AttnArgs a) {
   au32x4* Kr = lds;                       // [2][KP][RP]
   au32x4* Vt = Kr + 2 * KP * RP;          // [2][32][TP]
   au32x4* Qr = Vt + 2 * AD * TP;          // [2][AWQ][RP]
-  __shared__ float red[12];
+  __shared__ float red[24];
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * AWQ;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
   const float* base = a.qkv + (long long)b * S * 3 * E + h * AD;
@@ -172,9 +181,9 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(AttnArgs a) {
   for (int i = tid; i < 2 * KP * RP + 2 * AD * TP; i += 256) lds[i] = au32x4{0u, 0u, 0u, 0u};
   __syncthreads();
   float iq, ik, iv;
-  const float sq = pow2_scale(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), iq);
-  const float sk = pow2_scale(fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])), ik);
-  const float sv = pow2_scale(fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11])), iv);
+  const float sq = pow2_scale(red_max(red, 0), iq);
+  const float sk = pow2_scale(red_max(red, 1), ik);
+  const float sv = pow2_scale(red_max(red, 2), iv);
   stage_rows(base + (long long)q0 * ld, ld, nq, AWQ, a.scale, sq, Qr, AWQ, nullptr, 0);
   stage_rows(base + E, ld, S, KP, 1.f, sk, Kr, KP, nullptr, 0);
   stage_rows(base + 2 * E, ld, S, KP, 1.f, sv, nullptr, 0, Vt, TP);
@@ -272,7 +281,9 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(AttnArgs a) {
 // ------------------------------------------------------------------------------------------- backward, query side
 // S^T orientation (lane = query).  Recomputes P^T, dP^T = V dO^T (masked), D = sum_keys P dP, dS^T = P (dP - D) / sqrt(d),
 // then dQ^T = K^T dS^T.  Writes dQ into dqkv and D into Dq.
-__global__ __launch_bounds__(256) void attn_mfma_bwd_q_kernel(AttnArgs a) {
+template <int NW>      // waves per workgroup = 32-query tiles it owns (8: the whole 216-token head in one workgroup, 2 waves per SIMD)
+__global__ __launch_bounds__(NW * 64) void attn_mfma_bwd_q_kernel(AttnArgs a) {
+  constexpr int AWQ = NW * 32;
   extern __shared__ au32x4 lds[];
   const int S = a.S, E = a.E, H = a.H, NT = a.NT;
   const int KP = NT * 32, TP = (KP / 8) | 1;
@@ -281,8 +292,8 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_q_kernel(AttnArgs a) {
   au32x4* Kt = Vr + 2 * KP * RP;          // [2][32][TP]   K transposed (A of dQ^T = K^T dS^T)
   au32x4* Qr = Kt + 2 * AD * TP;          // [2][AWQ][RP]  Q rows       (B of the scores)
   au32x4* Gr = Qr + 2 * AWQ * RP;         // [2][AWQ][RP]  dO rows      (B of dP^T)
-  __shared__ float red[16];
-  __shared__ float dsmax[4];
+  __shared__ float red[32];
+  __shared__ float dsmax[8];
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * AWQ;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
   const float* base = a.qkv + (long long)b * S * 3 * E + h * AD;
@@ -290,21 +301,21 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_q_kernel(AttnArgs a) {
   const long long ld = 3LL * E;
   const int nq = min(AWQ, S - q0);
 
-  block_max3(rows_absmax(base + (long long)q0 * ld, ld, nq) * a.scale, red, 0);
-  block_max3(rows_absmax(base + E, ld, S), red, 1);
-  block_max3(rows_absmax(base + 2 * E, ld, S), red, 2);
-  block_max3(rows_absmax(gbase + (long long)q0 * E, E, nq), red, 3);
-  for (int i = tid; i < 4 * KP * RP + 2 * AD * TP + 4 * AWQ * RP; i += 256) lds[i] = au32x4{0u, 0u, 0u, 0u};
+  block_max3(rows_absmax<NW * 64>(base + (long long)q0 * ld, ld, nq) * a.scale, red, 0);
+  block_max3(rows_absmax<NW * 64>(base + E, ld, S), red, 1);
+  block_max3(rows_absmax<NW * 64>(base + 2 * E, ld, S), red, 2);
+  block_max3(rows_absmax<NW * 64>(gbase + (long long)q0 * E, E, nq), red, 3);
+  for (int i = tid; i < 4 * KP * RP + 2 * AD * TP + 4 * AWQ * RP; i += NW * 64) lds[i] = au32x4{0u, 0u, 0u, 0u};
   __syncthreads();
   float iq, ik, iv, ig;
-  const float sq = pow2_scale(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), iq);
-  const float sk = pow2_scale(fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])), ik);
-  const float sv = pow2_scale(fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11])), iv);
-  const float sg = pow2_scale(fmaxf(fmaxf(red[12], red[13]), fmaxf(red[14], red[15])), ig);
-  stage_rows(base + (long long)q0 * ld, ld, nq, AWQ, a.scale, sq, Qr, AWQ, nullptr, 0);
-  stage_rows(base + E, ld, S, KP, 1.f, sk, Kr, KP, Kt, TP);
-  stage_rows(base + 2 * E, ld, S, KP, 1.f, sv, Vr, KP, nullptr, 0);
-  stage_rows(gbase + (long long)q0 * E, E, nq, AWQ, 1.f, sg, Gr, AWQ, nullptr, 0);
+  const float sq = pow2_scale(red_max<NW>(red, 0), iq);
+  const float sk = pow2_scale(red_max<NW>(red, 1), ik);
+  const float sv = pow2_scale(red_max<NW>(red, 2), iv);
+  const float sg = pow2_scale(red_max<NW>(red, 3), ig);
+  stage_rows<NW * 64>(base + (long long)q0 * ld, ld, nq, AWQ, a.scale, sq, Qr, AWQ, nullptr, 0);
+  stage_rows<NW * 64>(base + E, ld, S, KP, 1.f, sk, Kr, KP, Kt, TP);
+  stage_rows<NW * 64>(base + 2 * E, ld, S, KP, 1.f, sv, Vr, KP, nullptr, 0);
+  stage_rows<NW * 64>(gbase + (long long)q0 * E, E, nq, AWQ, 1.f, sg, Gr, AWQ, nullptr, 0);
   __syncthreads();
 
   au32x4 bq[2][2], bg[2][2];
@@ -379,7 +390,10 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_q_kernel(AttnArgs a) {
   if (lane == 0) dsmax[wave] = dmx;
   __syncthreads();
   float ids;
-  const float sds = pow2_scale(fmaxf(fmaxf(dsmax[0], dsmax[1]), fmaxf(dsmax[2], dsmax[3])), ids);
+  float dall = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) dall = fmaxf(dall, dsmax[w]);
+  const float sds = pow2_scale(dall, ids);
   // dQ^T = K^T dS^T (rows = d, columns = queries)
   f32x16 dq;
 #pragma unroll
@@ -421,7 +435,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kv_kernel(AttnArgs a) {
   au32x4* Kr = Gt + 2 * AD * TP;          // [2][AWQ][RP]  this workgroup's K rows        (B of the scores)
   au32x4* Vr = Kr + 2 * AWQ * RP;         // [2][AWQ][RP]  this workgroup's V rows        (B of dP)
   float* tab = reinterpret_cast<float*>(Vr + 2 * AWQ * RP);   // [3][QP]: row max, 1 / row sum, D
-  __shared__ float red[16];
+  __shared__ float red[32];
   const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * AWQ;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
   const float* base = a.qkv + (long long)b * S * 3 * E + h * AD;
@@ -443,10 +457,10 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kv_kernel(AttnArgs a) {
     tab[2 * QP + i] = ok ? a.Dq[rbase + i] : 0.f;
   }
   float iq, ik, iv, ig;
-  const float sq = pow2_scale(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), iq);
-  const float sk = pow2_scale(fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])), ik);
-  const float sv = pow2_scale(fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11])), iv);
-  const float sg = pow2_scale(fmaxf(fmaxf(red[12], red[13]), fmaxf(red[14], red[15])), ig);
+  const float sq = pow2_scale(red_max(red, 0), iq);
+  const float sk = pow2_scale(red_max(red, 1), ik);
+  const float sv = pow2_scale(red_max(red, 2), iv);
+  const float sg = pow2_scale(red_max(red, 3), ig);
   stage_rows(base, ld, S, QP, a.scale, sq, Qr, QP, Qt, TP);
   stage_rows(gbase, E, S, QP, 1.f, sg, Gr, QP, Gt, TP);
   stage_rows(base + E + (long long)k0 * ld, ld, nk, AWQ, 1.f, sk, Kr, AWQ, nullptr, 0);
@@ -595,11 +609,14 @@ int cm_attention_mfma_bwd(const float* qkv, const float* stats, const float* o, 
   a.scale = 1.f / sqrtf((float)AD);
   a.rng = drop_p > 0.f ? rng : nullptr; a.site = site; a.drop_p = drop_p;
   const int kp = a.NT * 32, tp = (kp / 8) | 1;
-  const size_t lds_q = (size_t)(4 * kp * RP + 2 * AD * tp + 4 * AWQ * RP) * 16;
+  const int nwq = s > 128 ? 8 : 4;                              // query-side workgroup: 8 waves take a whole 216-token head
+  const size_t lds_q = (size_t)(4 * kp * RP + 2 * AD * tp + 4 * nwq * 32 * RP) * 16;
   const size_t lds_kv = (size_t)(4 * kp * RP + 4 * AD * tp + 4 * AWQ * RP) * 16 + (size_t)3 * kp * 4;
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute((const void*)attn_mfma_bwd_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) !=
+    if (hipFuncSetAttribute((const void*)attn_mfma_bwd_q_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) !=
+            hipSuccess ||
+        hipFuncSetAttribute((const void*)attn_mfma_bwd_q_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) !=
             hipSuccess ||
         hipFuncSetAttribute((const void*)attn_mfma_bwd_kv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) !=
             hipSuccess)
@@ -607,7 +624,8 @@ int cm_attention_mfma_bwd(const float* qkv, const float* stats, const float* o, 
     attr = true;
   }
   hipStream_t st = (hipStream_t)stream;
-  attn_mfma_bwd_q_kernel<<<dim3(cdiv(s, AWQ), h, b), 256, lds_q, st>>>(a);
+  if (nwq == 8) attn_mfma_bwd_q_kernel<8><<<dim3(cdiv(s, 256), h, b), 512, lds_q, st>>>(a);
+  else attn_mfma_bwd_q_kernel<4><<<dim3(cdiv(s, 128), h, b), 256, lds_q, st>>>(a);
   CM_CHECK_LAUNCH();
   attn_mfma_bwd_kv_kernel<<<dim3(cdiv(s, AWQ), h, b), 256, lds_kv, st>>>(a);
   CM_CHECK_LAUNCH();

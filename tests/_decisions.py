@@ -35,3 +35,19 @@ def hip_decisions(sv, delta=1e-5):
     for name, (ctx, _x) in zip(("up3.conv.", "up2.conv.", "up1.conv."), sv.ups):
         dec.amax[(name, None)] = _mask(ctx).cpu()
     return dec
+
+
+def transformer_relu_decisions(sv, delta=1e-5):
+    """cnn_transformer: the device path's ReLU on/off decisions (post-ReLU activations it saved, > 0) in the oracle's
+    layouts.  sv: climate_amd.cnn_transformer._Saved of a dropout-free forward."""
+    dec = oracle.Decisions(delta=delta)
+    B, _cin, H, W = sv.shape
+    e2, e = sv.y1.shape[1], sv.t0.shape[1]
+    dec.relu["encoder.0"] = (sv.y1 > 0).view(B, H // 2, W // 2, e2).permute(0, 3, 1, 2).cpu()     # token-major -> NCHW
+    dec.relu["encoder.2"] = (sv.t0 > 0).view(B, H // 4, W // 4, e).permute(0, 3, 1, 2).cpu()
+    for i, layer in enumerate(sv.layers):
+        h1 = layer[7]
+        dec.relu[("mlp", i)] = (h1 > 0).view(B, -1, h1.shape[1]).cpu()
+    dec.relu["decoder.0"] = (sv.dec1 > 0).cpu()
+    dec.relu["decoder.2"] = (sv.dec2 > 0).cpu()
+    return dec
