@@ -264,8 +264,18 @@ def test_cnn_transformer_train_mode_dropout_vs_oracle_with_device_masks(ops):
     masks = _device_masks(ops, m, rng, B, S, E, H, mlp, depth, p)
     frac = sum((v == 0).double().mean().item() for v in masks.values()) / len(masks)
     assert abs(frac - p) < 0.005
+    # the device's ReLU decisions (the same forward again, same {seed, counter}: bit-identical activations); MLP sites are
+    # left to the oracle (their stored activation is post-dropout)
+    from climate_amd import cnn_transformer as ct
+    from _decisions import transformer_relu_decisions
+    with torch.no_grad():
+        _, sv = ct.forward(m._param_dict(), x.cuda(), H, save=True, drop=(rng, p))
+    dec = transformer_relu_decisions(sv)
+    for k in [k for k in dec.relu if isinstance(k, tuple)]:
+        del dec.relu[k]
     pd = {k: v.double().requires_grad_() for k, v in P.items()}
-    lo = F.mse_loss(oracle.cnn_transformer_forward(pd, x.double(), H, masks=masks), y.double()); lo.backward()
+    lo = F.mse_loss(oracle.cnn_transformer_forward(pd, x.double(), H, masks=masks, decisions=dec), y.double()); lo.backward()
+    assert dec.violations == 0, dec.log
     assert abs(loss.item() - lo.item()) < 1e-5 * lo.item()
     named = dict(m.named_parameters())
     worst = 0.0
@@ -336,8 +346,14 @@ def test_cnn_transformer_config4_width_vs_oracle(ops):
     m = m.cuda()
     gen = torch.Generator("cpu").manual_seed(4)
     x = torch.randn(3, 5, 48, 72, generator=gen); y = torch.randn(3, 2, 48, 72, generator=gen)
+    from climate_amd import cnn_transformer as ct
+    from _decisions import transformer_relu_decisions
+    with torch.no_grad():
+        _, sv0 = ct.forward(m._param_dict(), x.cuda(), 8, save=True)
+    dec0 = transformer_relu_decisions(sv0)                 # (see the trainer part below)
     pd = {k: v.double().requires_grad_() for k, v in P.items()}
-    lo = F.mse_loss(oracle.cnn_transformer_forward(pd, x.double(), 8), y.double()); lo.backward()
+    lo = F.mse_loss(oracle.cnn_transformer_forward(pd, x.double(), 8, decisions=dec0), y.double()); lo.backward()
+    assert dec0.violations == 0, dec0.log
     pred = m(x.cuda()); lg = F.mse_loss(pred, y.cuda()); lg.backward()
     assert abs(lg.item() - lo.item()) < 1e-5 * lo.item()
     named = dict(m.named_parameters())
