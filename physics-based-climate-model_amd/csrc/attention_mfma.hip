@@ -424,7 +424,10 @@ __global__ __launch_bounds__(NW * 64) void attn_mfma_bwd_q_kernel(AttnArgs a) {
 // --------------------------------------------------------------------------------------------- backward, key side
 // S orientation (lane = key): S = Q K^T tiles (rows = queries).  dV^T = dO^T P_drop, dK^T = Q^T dS.  The row quantities
 // (max, 1/sum, D) belong to the ROWS here, i.e. 16 different queries per lane: read from LDS tables.
-__global__ __launch_bounds__(256) void attn_mfma_bwd_kv_kernel(AttnArgs a) {
+// 8 waves: wave w owns key tile w & 3 and the query tiles of parity w >> 2 (two waves per SIMD hide the latency of the
+// exp / hash / split arithmetic between the MFMAs -- with 152 KB of LDS only one workgroup fits a CU); the two partial
+// results of a key tile are combined through LDS at the end.
+__global__ __launch_bounds__(512) void attn_mfma_bwd_kv_kernel(AttnArgs a) {
   extern __shared__ au32x4 lds[];
   const int S = a.S, E = a.E, H = a.H, NT = a.NT;
   const int QP = NT * 32, TP = (QP / 8) | 1;
@@ -437,34 +440,35 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kv_kernel(AttnArgs a) {
   float* tab = reinterpret_cast<float*>(Vr + 2 * AWQ * RP);   // [3][QP]: row max, 1 / row sum, D
   __shared__ float red[32];
   const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * AWQ;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int wave = wave8 & 3, par = wave8 >> 2;
   const float* base = a.qkv + (long long)b * S * 3 * E + h * AD;
   const float* gbase = a.dO + (long long)b * S * E + h * AD;
   const long long ld = 3LL * E;
   const int nk = min(AWQ, S - k0);
 
-  block_max3(rows_absmax(base, ld, S) * a.scale, red, 0);
-  block_max3(rows_absmax(base + E + (long long)k0 * ld, ld, nk), red, 1);
-  block_max3(rows_absmax(base + 2 * E + (long long)k0 * ld, ld, nk), red, 2);
-  block_max3(rows_absmax(gbase, E, S), red, 3);
-  for (int i = tid; i < 4 * QP * RP + 4 * AD * TP + 4 * AWQ * RP; i += 256) lds[i] = au32x4{0u, 0u, 0u, 0u};
+  block_max3(rows_absmax<512>(base, ld, S) * a.scale, red, 0);
+  block_max3(rows_absmax<512>(base + E + (long long)k0 * ld, ld, nk), red, 1);
+  block_max3(rows_absmax<512>(base + 2 * E + (long long)k0 * ld, ld, nk), red, 2);
+  block_max3(rows_absmax<512>(gbase, E, S), red, 3);
+  for (int i = tid; i < 4 * QP * RP + 4 * AD * TP + 4 * AWQ * RP; i += 512) lds[i] = au32x4{0u, 0u, 0u, 0u};
   const long long rbase = ((long long)b * H + h) * S;
   __syncthreads();
-  for (int i = tid; i < QP; i += 256) {
+  for (int i = tid; i < QP; i += 512) {
     const bool ok = i < S;
     tab[i] = ok ? a.stats[2 * (rbase + i)] : 0.f;
     tab[QP + i] = ok ? 1.f / a.stats[2 * (rbase + i) + 1] : 0.f;
     tab[2 * QP + i] = ok ? a.Dq[rbase + i] : 0.f;
   }
   float iq, ik, iv, ig;
-  const float sq = pow2_scale(red_max(red, 0), iq);
-  const float sk = pow2_scale(red_max(red, 1), ik);
-  const float sv = pow2_scale(red_max(red, 2), iv);
-  const float sg = pow2_scale(red_max(red, 3), ig);
-  stage_rows(base, ld, S, QP, a.scale, sq, Qr, QP, Qt, TP);
-  stage_rows(gbase, E, S, QP, 1.f, sg, Gr, QP, Gt, TP);
-  stage_rows(base + E + (long long)k0 * ld, ld, nk, AWQ, 1.f, sk, Kr, AWQ, nullptr, 0);
-  stage_rows(base + 2 * E + (long long)k0 * ld, ld, nk, AWQ, 1.f, sv, Vr, AWQ, nullptr, 0);
+  const float sq = pow2_scale(red_max<8>(red, 0), iq);
+  const float sk = pow2_scale(red_max<8>(red, 1), ik);
+  const float sv = pow2_scale(red_max<8>(red, 2), iv);
+  const float sg = pow2_scale(red_max<8>(red, 3), ig);
+  stage_rows<512>(base, ld, S, QP, a.scale, sq, Qr, QP, Qt, TP);
+  stage_rows<512>(gbase, E, S, QP, 1.f, sg, Gr, QP, Gt, TP);
+  stage_rows<512>(base + E + (long long)k0 * ld, ld, nk, AWQ, 1.f, sk, Kr, AWQ, nullptr, 0);
+  stage_rows<512>(base + 2 * E + (long long)k0 * ld, ld, nk, AWQ, 1.f, sv, Vr, AWQ, nullptr, 0);
   __syncthreads();
 
   au32x4 bk[2][2], bv[2][2];
@@ -491,7 +495,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kv_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dv[r] = 0.f; dk[r] = 0.f; }
 #pragma unroll 1
-    for (int qt = 0; qt < NT; ++qt) {
+    for (int qt = par; qt < NT; qt += 2) {
       f32x16 c, g;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { c[r] = 0.f; g[r] = 0.f; }
@@ -549,17 +553,28 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kv_kernel(AttnArgs a) {
         }
       }
     }
-    if (klive) {
-      const float ids = be_run <= 13u ? 0.f : __uint_as_float((be_run - 13u) << 23);   // 2^(be - 140)
-      const float iov = ig * (1.f / SP), iok = iq * ids;
+    // each wave undoes ITS scales (the two waves of a key tile ran their own running maxima), then the odd-parity wave
+    // hands its partial to the even one through LDS (the operand images are dead by now)
+    const float ids = be_run <= 13u ? 0.f : __uint_as_float((be_run - 13u) << 23);   // 2^(be - 140)
+    const float iov = ig * (1.f / SP), iok = iq * ids;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dv[r] *= iov; dk[r] *= iok; }
+    __syncthreads();
+    float* comb = reinterpret_cast<float*>(lds) + (size_t)wave * 32 * 64;
+    if (par == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { comb[r * 64 + lane] = dv[r]; comb[(16 + r) * 64 + lane] = dk[r]; }
+    }
+    __syncthreads();
+    if (par == 0 && klive) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dv[r] += comb[r * 64 + lane]; dk[r] += comb[(16 + r) * 64 + lane]; }
       float* vp = a.dqkv + ((long long)b * S + key) * 3 * E + 2 * E + h * AD;
       float* kp = a.dqkv + ((long long)b * S + key) * 3 * E + E + h * AD;
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        *reinterpret_cast<float4*>(vp + 8 * g4 + 4 * half) =
-            make_float4(dv[4 * g4] * iov, dv[4 * g4 + 1] * iov, dv[4 * g4 + 2] * iov, dv[4 * g4 + 3] * iov);
-        *reinterpret_cast<float4*>(kp + 8 * g4 + 4 * half) =
-            make_float4(dk[4 * g4] * iok, dk[4 * g4 + 1] * iok, dk[4 * g4 + 2] * iok, dk[4 * g4 + 3] * iok);
+        *reinterpret_cast<float4*>(vp + 8 * g4 + 4 * half) = make_float4(dv[4 * g4], dv[4 * g4 + 1], dv[4 * g4 + 2], dv[4 * g4 + 3]);
+        *reinterpret_cast<float4*>(kp + 8 * g4 + 4 * half) = make_float4(dk[4 * g4], dk[4 * g4 + 1], dk[4 * g4 + 2], dk[4 * g4 + 3]);
       }
     }
   }
@@ -627,7 +642,7 @@ int cm_attention_mfma_bwd(const float* qkv, const float* stats, const float* o, 
   if (nwq == 8) attn_mfma_bwd_q_kernel<8><<<dim3(cdiv(s, 256), h, b), 512, lds_q, st>>>(a);
   else attn_mfma_bwd_q_kernel<4><<<dim3(cdiv(s, 128), h, b), 256, lds_q, st>>>(a);
   CM_CHECK_LAUNCH();
-  attn_mfma_bwd_kv_kernel<<<dim3(cdiv(s, AWQ), h, b), 256, lds_kv, st>>>(a);
+  attn_mfma_bwd_kv_kernel<<<dim3(cdiv(s, AWQ), h, b), 512, lds_kv, st>>>(a);
   CM_CHECK_LAUNCH();
   return 0;
 }
