@@ -94,26 +94,81 @@ __device__ __forceinline__ void gemm_store_tile(gu32x4* __restrict__ L, int tid,
   }
 }
 
-template <bool TA, bool TB>
+// 64-row operand tile (the B side of the narrow 128 x 64 workgroup tile): one record of 8 consecutive k per thread
+//   k-contiguous storage: thread -> (row = tid / 4, k octet = tid % 4): two 16-byte loads
+//   row-contiguous storage: thread -> (k octet = tid / 64, row = lane): 8 strided loads of 64 consecutive rows each
+template <bool TRANS>
+__device__ __forceinline__ void gemm_load_tile64(const float* __restrict__ P, long long ld, int rows, int K, int r0, int k0,
+                                                 int tid, float (&v)[16]) {
+  if constexpr (!TRANS) {
+    const int row = r0 + (tid >> 2), kk = k0 + (tid & 3) * 8;
+    const bool rok = row < rows;
+    const float* src = P + (long long)(rok ? row : 0) * ld + kk;
+    const bool vec = (ld & 3) == 0 && (((uintptr_t)P) & 15) == 0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (vec && rok && kk + 4 * q + 4 <= K) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(src + 4 * q);
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * q + e] = (rok && kk + 4 * q + e < K) ? src[4 * q + e] : 0.f;
+      }
+    }
+  } else {
+    const int ko = tid >> 6, row = r0 + (tid & 63);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + ko * 8 + j;
+      v[j] = (row < rows && k < K) ? P[(long long)k * ld + row] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int j = 8; j < 16; ++j) v[j] = 0.f;
+}
+
+template <bool TRANS>
+__device__ __forceinline__ void gemm_store_tile64(gu32x4* __restrict__ L, int tid, const float (&v)[16], float sc) {
+  const int row = TRANS ? (tid & 63) : (tid >> 2), oct = TRANS ? (tid >> 6) : (tid & 3);
+  gu32x4 ph, pl;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    unsigned a_, b_;
+    split2_pair_f16(v[2 * q] * sc, v[2 * q + 1] * sc, a_, b_);
+    ph[q] = a_; pl[q] = b_;
+  }
+  L[(0 * 4 + oct) * 128 + row] = ph;
+  L[(1 * 4 + oct) * 128 + row] = pl;
+}
+
+// BN = 128: 2 x 2 waves of 64 x 64;  BN = 64: 4 x 1 waves of 32 x 64 (twice the workgroups for the narrow GEMMs --
+// 13824 x 256 x 256 is 216 tiles of 128 x 128 on 256 CUs, i.e. one 4-wave workgroup per CU and nothing to hide the
+// staging arithmetic behind).
+template <bool TA, bool TB, int BN = 128>
 __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
+  constexpr int TI = BN == 128 ? 2 : 1;
   __shared__ gu32x4 Al[2 * 4 * 128], Bl[2 * 4 * 128];   // [piece][k octet][row / column]
   __shared__ unsigned smax[2][2];                       // [stage parity][A, B] posted maxima
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+  const int wr = BN == 128 ? wave >> 1 : wave, wc = BN == 128 ? wave & 1 : 0;
+  const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * BN;
   const int nstage = (a.K + GBK - 1) / GBK;
   const int sps = (nstage + a.ksplit - 1) / a.ksplit;
   const int s_begin = blockIdx.z * sps, s_end = min(nstage, s_begin + sps);
   if (s_begin >= s_end) return;
 
-  f32x16 acc[2][2];
+  f32x16 acc[TI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  auto load_b = [&](int k0, float (&v)[16]) {
+    if constexpr (BN == 128) gemm_load_tile<TB>(a.B, a.ldb, a.N, a.K, n0, k0, tid, v);
+    else gemm_load_tile64<TB>(a.B, a.ldb, a.N, a.K, n0, k0, tid, v);
+  };
 
   if (tid < 4) smax[tid >> 1][tid & 1] = 0u;
   __syncthreads();
@@ -131,7 +186,7 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
     }
   };
   gemm_load_tile<TA>(a.A, a.lda, a.M, a.K, m0, s_begin * GBK, tid, va);
-  gemm_load_tile<TB>(a.B, a.ldb, a.N, a.K, n0, s_begin * GBK, tid, vb);
+  load_b(s_begin * GBK, vb);
   post(0);
   __syncthreads();
   for (int s = s_begin; s < s_end; ++s) {
@@ -142,7 +197,7 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
         const int d = (int)(max(na, 13u) - max(bea, 13u)) + (int)(max(nb, 13u) - max(beb, 13u));
         const float f = (bea == 0 || beb == 0 || d > 126) ? 0.f : __uint_as_float((unsigned)(127 - d) << 23);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -152,26 +207,29 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
     }
     const float sa = __uint_as_float((267u - max(bea, 13u)) << 23), sb = __uint_as_float((267u - max(beb, 13u)) << 23);
     gemm_store_tile<TA>(Al, tid, va, sa);
-    gemm_store_tile<TB>(Bl, tid, vb, sb);
+    if constexpr (BN == 128) gemm_store_tile<TB>(Bl, tid, vb, sb);
+    else gemm_store_tile64<TB>(Bl, tid, vb, sb);
     __syncthreads();
     if (tid < 2) smax[par][tid] = 0u;
     if (s + 1 < s_end) {
       gemm_load_tile<TA>(a.A, a.lda, a.M, a.K, m0, (s + 1) * GBK, tid, va);
-      gemm_load_tile<TB>(a.B, a.ldb, a.N, a.K, n0, (s + 1) * GBK, tid, vb);
+      load_b((s + 1) * GBK, vb);
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {         // two 16-deep MFMA k-steps per stage; the lane half picks the octet
       const int oct = ks * 2 + half;
-      f16x8 af[2][2], bf[2][2];              // [piece][tile]
+      f16x8 af[2][TI], bf[2][2];             // [piece][tile]
 #pragma unroll
-      for (int pc = 0; pc < 2; ++pc)
+      for (int pc = 0; pc < 2; ++pc) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          af[pc][t] = __builtin_bit_cast(f16x8, Al[(pc * 4 + oct) * 128 + wr * 64 + t * 32 + l31]);
+        for (int t = 0; t < TI; ++t)
+          af[pc][t] = __builtin_bit_cast(f16x8, Al[(pc * 4 + oct) * 128 + wr * (32 * TI) + t * 32 + l31]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
           bf[pc][t] = __builtin_bit_cast(f16x8, Bl[(pc * 4 + oct) * 128 + wc * 64 + t * 32 + l31]);
-        }
+      }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
@@ -188,7 +246,7 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
   const float ib = beb <= 13u ? 0.f : __uint_as_float((beb - 13u) << 23);
   const DropSite drop = cm_drop_site(a.rng, a.site, a.drop_p);
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int n = n0 + wc * 64 + j * 32 + l31;
@@ -196,7 +254,7 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
       const float bv = (a.bias && blockIdx.z == 0) ? a.bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int m = m0 + wr * (32 * TI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (m >= a.M) continue;
         float v = (acc[i][j][r] * ia) * ib + bv;
         if (a.ksplit > 1) {
@@ -233,8 +291,19 @@ int cm_gemm_h3(const float* a, long long lda, int trans_a, const float* b, long 
   g.rng = drop_p > 0.f ? rng : nullptr; g.site = site; g.drop_p = drop_p; g.mask_scale = mask_scale;
   const int nstage = cdiv(k, GBK);
   g.ksplit = ksplit > nstage ? nstage : ksplit;
-  const dim3 grid(cdiv(n, GBN), cdiv(m, GBM), g.ksplit);
   hipStream_t st = (hipStream_t)stream;
+  // narrow tiles when 128 x 128 tiles would not even give every CU two workgroups
+  const bool narrow = (long long)cdiv(n, GBN) * cdiv(m, GBM) * g.ksplit < 512;
+  if (narrow) {
+    const dim3 grid(cdiv(n, 64), cdiv(m, GBM), g.ksplit);
+    if (!trans_a && !trans_b) gemm_h3_kernel<false, false, 64><<<grid, 256, 0, st>>>(g);
+    else if (!trans_a && trans_b) gemm_h3_kernel<false, true, 64><<<grid, 256, 0, st>>>(g);
+    else if (trans_a && trans_b) gemm_h3_kernel<true, true, 64><<<grid, 256, 0, st>>>(g);
+    else gemm_h3_kernel<true, false, 64><<<grid, 256, 0, st>>>(g);
+    CM_CHECK_LAUNCH();
+    return 0;
+  }
+  const dim3 grid(cdiv(n, GBN), cdiv(m, GBM), g.ksplit);
   if (!trans_a && !trans_b) gemm_h3_kernel<false, false><<<grid, 256, 0, st>>>(g);
   else if (!trans_a && trans_b) gemm_h3_kernel<false, true><<<grid, 256, 0, st>>>(g);
   else if (trans_a && trans_b) gemm_h3_kernel<true, true><<<grid, 256, 0, st>>>(g);
