@@ -13,6 +13,7 @@
 // one power of two per operand from the RUNNING maximum of what the workgroup has staged (exact, no calibration); the
 // accumulators follow when a scale shrinks.  Workgroup = 128 x 128 output tile, 4 waves as 2 x 2, 2 x 2 MFMA tiles per
 // wave, 32-deep K stages; blockIdx.z splits K (atomic accumulation into a zeroed C).
+#include <stdlib.h>
 #include "common.h"
 #include "split_f16.h"
 #include "../../include/climate_hip.h"
@@ -292,8 +293,9 @@ int cm_gemm_h3(const float* a, long long lda, int trans_a, const float* b, long 
   const int nstage = cdiv(k, GBK);
   g.ksplit = ksplit > nstage ? nstage : ksplit;
   hipStream_t st = (hipStream_t)stream;
-  // narrow tiles when 128 x 128 tiles would not even give every CU two workgroups
-  const bool narrow = (long long)cdiv(n, GBN) * cdiv(m, GBM) * g.ksplit < 512;
+  // narrow tiles when 128 x 128 tiles would give fewer than ~4 workgroups per CU (CM_GEMM_NARROW: 512 -> 9665, 1024 -> 9765, always -> 9755, never -> 8749 samples/s at config 4)
+  static const long long narrow_below = getenv("CM_GEMM_NARROW") ? atoll(getenv("CM_GEMM_NARROW")) : 1024;
+  const bool narrow = (long long)cdiv(n, GBN) * cdiv(m, GBM) * g.ksplit < narrow_below;
   if (narrow) {
     const dim3 grid(cdiv(n, 64), cdiv(m, GBM), g.ksplit);
     if (!trans_a && !trans_b) gemm_h3_kernel<false, false, 64><<<grid, 256, 0, st>>>(g);
