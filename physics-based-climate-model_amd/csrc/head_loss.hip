@@ -154,61 +154,53 @@ __global__ __launch_bounds__(256) void head_mse_bwd_kernel(const float* __restri
   for (int i = tid; i < OC; i += 256) bsh[i] = b[i];
   __syncthreads();
   float dbp[OCT], lsum = 0.f;
+  // One pixel per thread (the host launches ppb = 256): pred, the loss term and dpred are computed ONCE, then the
+  // channels are walked in chunks of HB_CC whose dW partials live in registers (the chunked walk re-reads x from the
+  // cache).  (The first version recomputed pred inside every chunk: C / HB_CC + 1 passes over the channels.)
+  const int p = p_begin + tid;
+  const bool live = p < p_end;
+  const float* xp = x + (long long)n * sx + (live ? p : p_begin);
+  float dp[OCT];
+  {
+    float acc[OCT];
 #pragma unroll
-  for (int o = 0; o < OCT; ++o) dbp[o] = 0.f;
-  // NOTE: one pixel per thread per pass of the outer loop; the dW partials of a 16-channel chunk live in registers
-  // across the thread's pixels, so the chunk loop is outermost and pred is recomputed per chunk only when a thread
-  // owns more than one pixel (ppb <= 256 in practice: exactly one pixel per thread).
-  for (int c0 = 0; c0 < C; c0 += HB_CC) {
-    float dwp[OCT][HB_CC];
-#pragma unroll
-    for (int o = 0; o < OCT; ++o)
-#pragma unroll
-      for (int j = 0; j < HB_CC; ++j) dwp[o][j] = 0.f;
-    for (int p = p_begin + tid; p < p_end; p += 256) {
-      const float* xp = x + (long long)n * sx + p;
-      float acc[OCT];
-#pragma unroll
-      for (int o = 0; o < OCT; ++o) acc[o] = (o < OC) ? bsh[o] : 0.f;
+    for (int o = 0; o < OCT; ++o) acc[o] = (o < OC) ? bsh[o] : 0.f;
+    if (live) {
       for (int c = 0; c < C; ++c) {
         const float xv = xp[(long long)c * HW];
 #pragma unroll
         for (int o = 0; o < OCT; ++o)
           if (o < OC) acc[o] += wsh[o * C + c] * xv;
       }
-      float dp[OCT];
+    }
 #pragma unroll
-      for (int o = 0; o < OCT; ++o) {
-        float d = 0.f;
-        if (o < OC) {
-          d = acc[o] - y[((long long)n * OC + o) * HW + p];
-          if (c0 == 0) {
-            lsum += d * d;
-            if (pred_out) pred_out[((long long)n * OC + o) * HW + p] = acc[o];
-          }
-        }
-        dp[o] = 2.f * d * inv_total;
+    for (int o = 0; o < OCT; ++o) {
+      float d = 0.f;
+      if (o < OC && live) {
+        d = acc[o] - y[((long long)n * OC + o) * HW + p];
+        lsum += d * d;
+        if (pred_out) pred_out[((long long)n * OC + o) * HW + p] = acc[o];
       }
-      if (c0 == 0) {
+      dp[o] = 2.f * d * inv_total;
+      dbp[o] = dp[o];
+    }
+  }
+  for (int c0 = 0; c0 < C; c0 += HB_CC) {
+    float dwp[OCT][HB_CC];
 #pragma unroll
-        for (int o = 0; o < OCT; ++o) dbp[o] += dp[o];
+    for (int j = 0; j < HB_CC; ++j) {
+      const int c = c0 + j;
+      float xv = 0.f;
+      if (c < C && live) {
+        xv = xp[(long long)c * HW];
+        float g = 0.f;
+#pragma unroll
+        for (int o = 0; o < OCT; ++o)
+          if (o < OC) g += wsh[o * C + c] * dp[o];
+        dx[(long long)n * sdx + (long long)c * HW + p] = g;
       }
 #pragma unroll
-      for (int j = 0; j < HB_CC; ++j) {
-        const int c = c0 + j;
-        if (c < C) {
-          const float xv = xp[(long long)c * HW];
-          float g = 0.f;
-#pragma unroll
-          for (int o = 0; o < OCT; ++o) {
-            if (o < OC) {
-              g += wsh[o * C + c] * dp[o];
-              dwp[o][j] += dp[o] * xv;
-            }
-          }
-          dx[(long long)n * sdx + (long long)c * HW + p] = g;
-        }
-      }
+      for (int o = 0; o < OCT; ++o) dwp[o][j] = dp[o] * xv;
     }
 #pragma unroll
     for (int o = 0; o < OCT; ++o) {
