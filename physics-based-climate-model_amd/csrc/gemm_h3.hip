@@ -145,27 +145,35 @@ __device__ __forceinline__ void gemm_store_tile64(gu32x4* __restrict__ L, int ti
 // BN = 128: 2 x 2 waves of 64 x 64;  BN = 64: 4 x 1 waves of 32 x 64 (twice the workgroups for the narrow GEMMs --
 // 13824 x 256 x 256 is 216 tiles of 128 x 128 on 256 CUs, i.e. one 4-wave workgroup per CU and nothing to hide the
 // staging arithmetic behind).
-template <bool TA, bool TB, int BN = 128>
+// BM = BN = 64: 2 x 2 waves of 32 x 32 (four times the workgroups: for the GEMMs whose 128 x 64 tiling still leaves the
+// chip under ~4 workgroups per CU).
+template <bool TA, bool TB, int BN = 128, int BM = 128>
 __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
-  constexpr int TI = BN == 128 ? 2 : 1;
+  static_assert(BM == 128 || (BM == 64 && BN == 64), "tile shapes: 128x128, 128x64, 64x64");
+  constexpr int TI = (BM == 128 && BN == 128) ? 2 : 1, TJ = BM == 64 ? 1 : 2;
   __shared__ gu32x4 Al[2 * 4 * 128], Bl[2 * 4 * 128];   // [piece][k octet][row / column]
   __shared__ unsigned smax[2][2];                       // [stage parity][A, B] posted maxima
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
-  const int wr = BN == 128 ? wave >> 1 : wave, wc = BN == 128 ? wave & 1 : 0;
-  const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * BN;
+  const int wr_off = BM == 64 ? (wave >> 1) * 32 : (BN == 128 ? (wave >> 1) * 64 : wave * 32);   // this wave's rows ..
+  const int wc_off = BM == 64 ? (wave & 1) * 32 : (BN == 128 ? (wave & 1) * 64 : 0);            // .. and columns in the tile
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int nstage = (a.K + GBK - 1) / GBK;
   const int sps = (nstage + a.ksplit - 1) / a.ksplit;
   const int s_begin = blockIdx.z * sps, s_end = min(nstage, s_begin + sps);
   if (s_begin >= s_end) return;
 
-  f32x16 acc[TI][2];
+  f32x16 acc[TI][TJ];
 #pragma unroll
   for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  auto load_a = [&](int k0, float (&v)[16]) {
+    if constexpr (BM == 128) gemm_load_tile<TA>(a.A, a.lda, a.M, a.K, m0, k0, tid, v);
+    else gemm_load_tile64<TA>(a.A, a.lda, a.M, a.K, m0, k0, tid, v);
+  };
   auto load_b = [&](int k0, float (&v)[16]) {
     if constexpr (BN == 128) gemm_load_tile<TB>(a.B, a.ldb, a.N, a.K, n0, k0, tid, v);
     else gemm_load_tile64<TB>(a.B, a.ldb, a.N, a.K, n0, k0, tid, v);
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
       atomicMax(&smax[par][1], __float_as_uint(mb));
     }
   };
-  gemm_load_tile<TA>(a.A, a.lda, a.M, a.K, m0, s_begin * GBK, tid, va);
+  load_a(s_begin * GBK, va);
   load_b(s_begin * GBK, vb);
   post(0);
   __syncthreads();
@@ -200,39 +208,40 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] *= f;
       }
       bea = na; beb = nb;
     }
     const float sa = __uint_as_float((267u - max(bea, 13u)) << 23), sb = __uint_as_float((267u - max(beb, 13u)) << 23);
-    gemm_store_tile<TA>(Al, tid, va, sa);
+    if constexpr (BM == 128) gemm_store_tile<TA>(Al, tid, va, sa);
+    else gemm_store_tile64<TA>(Al, tid, va, sa);
     if constexpr (BN == 128) gemm_store_tile<TB>(Bl, tid, vb, sb);
     else gemm_store_tile64<TB>(Bl, tid, vb, sb);
     __syncthreads();
     if (tid < 2) smax[par][tid] = 0u;
     if (s + 1 < s_end) {
-      gemm_load_tile<TA>(a.A, a.lda, a.M, a.K, m0, (s + 1) * GBK, tid, va);
+      load_a((s + 1) * GBK, va);
       load_b((s + 1) * GBK, vb);
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {         // two 16-deep MFMA k-steps per stage; the lane half picks the octet
       const int oct = ks * 2 + half;
-      f16x8 af[2][TI], bf[2][2];             // [piece][tile]
+      f16x8 af[2][TI], bf[2][TJ];            // [piece][tile]
 #pragma unroll
       for (int pc = 0; pc < 2; ++pc) {
 #pragma unroll
         for (int t = 0; t < TI; ++t)
-          af[pc][t] = __builtin_bit_cast(f16x8, Al[(pc * 4 + oct) * 128 + wr * (32 * TI) + t * 32 + l31]);
+          af[pc][t] = __builtin_bit_cast(f16x8, Al[(pc * 4 + oct) * 128 + wr_off + t * 32 + l31]);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-          bf[pc][t] = __builtin_bit_cast(f16x8, Bl[(pc * 4 + oct) * 128 + wc * 64 + t * 32 + l31]);
+        for (int t = 0; t < TJ; ++t)
+          bf[pc][t] = __builtin_bit_cast(f16x8, Bl[(pc * 4 + oct) * 128 + wc_off + t * 32 + l31]);
       }
 #pragma unroll
       for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < TJ; ++j) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
@@ -249,13 +258,13 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
 #pragma unroll
   for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wc * 64 + j * 32 + l31;
+    for (int j = 0; j < TJ; ++j) {
+      const int n = n0 + wc_off + j * 32 + l31;
       if (n >= a.N) continue;
       const float bv = (a.bias && blockIdx.z == 0) ? a.bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wr * (32 * TI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int m = m0 + wr_off + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (m >= a.M) continue;
         float v = (acc[i][j][r] * ia) * ib + bv;
         if (a.ksplit > 1) {
@@ -296,6 +305,19 @@ int cm_gemm_h3(const float* a, long long lda, int trans_a, const float* b, long 
   // narrow tiles when 128 x 128 tiles would give fewer than ~4 workgroups per CU (CM_GEMM_NARROW: 512 -> 9665, 1024 -> 9765, always -> 9755, never -> 8749 samples/s at config 4)
   static const long long narrow_below = getenv("CM_GEMM_NARROW") ? atoll(getenv("CM_GEMM_NARROW")) : 1024;
   const bool narrow = (long long)cdiv(n, GBN) * cdiv(m, GBM) * g.ksplit < narrow_below;
+  // 64 x 64 tiles by default (CM_GEMM_SMALL=<n>: only below n workgroups of 128 x 64; 0 -> 10062, 1024 -> 10293,
+  // always -> 10354 samples/s at config 4: at these sizes four times the workgroups beat the better LDS reuse of the
+  // larger tiles everywhere)
+  static const long long small_below = getenv("CM_GEMM_SMALL") ? atoll(getenv("CM_GEMM_SMALL")) : (1LL << 40);
+  if ((long long)cdiv(n, 64) * cdiv(m, GBM) * g.ksplit < small_below) {      // 64 x 64 tiles
+    const dim3 grid(cdiv(n, 64), cdiv(m, 64), g.ksplit);
+    if (!trans_a && !trans_b) gemm_h3_kernel<false, false, 64, 64><<<grid, 256, 0, st>>>(g);
+    else if (!trans_a && trans_b) gemm_h3_kernel<false, true, 64, 64><<<grid, 256, 0, st>>>(g);
+    else if (trans_a && trans_b) gemm_h3_kernel<true, true, 64, 64><<<grid, 256, 0, st>>>(g);
+    else gemm_h3_kernel<true, false, 64, 64><<<grid, 256, 0, st>>>(g);
+    CM_CHECK_LAUNCH();
+    return 0;
+  }
   if (narrow) {
     const dim3 grid(cdiv(n, 64), cdiv(m, GBM), g.ksplit);
     if (!trans_a && !trans_b) gemm_h3_kernel<false, false, 64><<<grid, 256, 0, st>>>(g);
