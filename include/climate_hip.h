@@ -273,11 +273,12 @@ int cm_eval_finalize(const double* moments, const double* lat_w_dev, double coun
  * atomics into a C the caller zeroed (weight gradients: C = dY^T X with trans_a = trans_b = 1).
  * Dropout (nn.Dropout in the encoder layer, src/cnn_transformer.py:26-33): with rng != null and drop_p > 0 the value is
  * multiplied by the counter-based mask of (rng, site) -- see cm_dropout -- after bias / ReLU and BEFORE the residual
- * (x + dropout(sublayer(x))); mask_scale multiplies what `mask` keeps (ReLU backward through a dropped activation).  */
+ * (x + dropout(sublayer(x))); mask_scale multiplies what `mask` keeps (ReLU backward through a dropped activation).
+ * tile: workgroup tile, 0 = the library's choice (64 x 64 at these sizes), 1 = 128 x 128, 2 = 128 x 64, 3 = 64 x 64.      */
 int cm_gemm_h3(const float* a, long long lda, int trans_a, const float* b, long long ldb, int trans_b, float* c,
                long long ldc, const float* bias, const float* resid, long long ldr, int res_rows, const float* mask,
                long long ldm, float mask_scale, int relu, const unsigned* rng, unsigned site, float drop_p, int m, int n,
-               int k, int ksplit, cm_stream stream);
+               int k, int ksplit, int tile, cm_stream stream);
 /* post-norm residual LayerNorm, eps as given (nn.LayerNorm default 1e-5): sum_out = x + resid (nullable resid; kept for
  * the backward), y = LN(sum_out) * gamma + beta, stats[m][2] = {mean, rstd}.  e <= 1024.                          */
 int cm_layernorm_fwd(const float* x, const float* resid, const float* gamma, const float* beta, float* sum_out, float* y,

@@ -287,7 +287,7 @@ extern "C" {
 int cm_gemm_h3(const float* a, long long lda, int trans_a, const float* b, long long ldb, int trans_b, float* c,
                long long ldc, const float* bias, const float* resid, long long ldr, int res_rows, const float* mask,
                long long ldm, float mask_scale, int relu, const unsigned* rng, unsigned site, float drop_p, int m, int n,
-               int k, int ksplit, cm_stream stream) {
+               int k, int ksplit, int tile, cm_stream stream) {
   if (m <= 0 || n <= 0 || k <= 0 || !a || !b || !c || lda <= 0 || ldb <= 0 || ldc < n) return -22;
   if (ksplit < 1) ksplit = 1;
   if (ksplit > 1 && (resid || mask || relu || (rng && drop_p > 0.f))) return -22;   // split K accumulates raw sums
@@ -309,7 +309,9 @@ int cm_gemm_h3(const float* a, long long lda, int trans_a, const float* b, long 
   // always -> 10354 samples/s at config 4: at these sizes four times the workgroups beat the better LDS reuse of the
   // larger tiles everywhere)
   static const long long small_below = getenv("CM_GEMM_SMALL") ? atoll(getenv("CM_GEMM_SMALL")) : (1LL << 40);
-  if ((long long)cdiv(n, 64) * cdiv(m, GBM) * g.ksplit < small_below) {      // 64 x 64 tiles
+  if (tile < 0 || tile > 3) return -22;
+  const bool want_small = tile == 3 || (tile == 0 && (long long)cdiv(n, 64) * cdiv(m, GBM) * g.ksplit < small_below);
+  if (want_small) {      // 64 x 64 tiles
     const dim3 grid(cdiv(n, 64), cdiv(m, 64), g.ksplit);
     if (!trans_a && !trans_b) gemm_h3_kernel<false, false, 64, 64><<<grid, 256, 0, st>>>(g);
     else if (!trans_a && trans_b) gemm_h3_kernel<false, true, 64, 64><<<grid, 256, 0, st>>>(g);
@@ -318,7 +320,7 @@ int cm_gemm_h3(const float* a, long long lda, int trans_a, const float* b, long 
     CM_CHECK_LAUNCH();
     return 0;
   }
-  if (narrow) {
+  if (tile == 2 || (tile == 0 && narrow)) {
     const dim3 grid(cdiv(n, 64), cdiv(m, GBM), g.ksplit);
     if (!trans_a && !trans_b) gemm_h3_kernel<false, false, 64><<<grid, 256, 0, st>>>(g);
     else if (!trans_a && trans_b) gemm_h3_kernel<false, true, 64><<<grid, 256, 0, st>>>(g);

@@ -609,7 +609,7 @@ def _drop_args(drop):
 
 
 def gemm(a, b, m, n, k, trans_a=False, trans_b=False, bias=None, resid=None, res_rows=0, mask=None, relu=False,
-         out=None, ksplit=1, lda=None, ldb=None, drop=None, mask_scale=1.0):
+         out=None, ksplit=1, lda=None, ldb=None, drop=None, mask_scale=1.0, tile=0):
     """out[m, n] = relu?(op(a) op(b) + bias) + resid (masked) on the fp16x3 GEMM kernel (cm_gemm_h3).  a / b are 2-D
     row-major tensors: a is [m, k] (or [k, m] when trans_a), b is [n, k] -- an nn.Linear weight, out = a b^T -- (or
     [k, n] when trans_b).  ksplit > 1 ACCUMULATES into ``out`` (which the caller zeroed).  ``drop`` = (rng, site, p):
@@ -621,7 +621,7 @@ def gemm(a, b, m, n, k, trans_a=False, trans_b=False, bias=None, resid=None, res
     check(lib.cm_gemm_h3(_p(a), lda, int(trans_a), _p(b), ldb, int(trans_b), _p(out), out.stride(0), _p(bias), _p(resid),
                          0 if resid is None else resid.stride(0), res_rows, _p(mask),
                          0 if mask is None else mask.stride(0), float(mask_scale), int(relu), *_drop_args(drop), m, n, k,
-                         ksplit, _stream()), "gemm_h3")
+                         ksplit, int(tile), _stream()), "gemm_h3")
     return out
 
 

@@ -53,7 +53,7 @@ def _wgrad_h3_bytes(a):
     return _wgrad_bytes(a[:8] + a[10:])
 
 
-def _gemm_flops(a):        # cm_gemm_h3(a, lda, ta, b, ldb, tb, c, ldc, bias, resid, ldr, res_rows, mask, ldm, mask_scale, relu, rng, site, p, m, n, k, ..)
+def _gemm_flops(a):        # cm_gemm_h3(a, lda, ta, b, ldb, tb, c, ldc, bias, resid, ldr, res_rows, mask, ldm, mask_scale, relu, rng, site, p, m, n, k, ksplit, tile, stream)
     return 2.0 * a[19] * a[20] * a[21]
 
 

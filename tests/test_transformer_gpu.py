@@ -28,23 +28,24 @@ def rnd(*shape, seed=0, scale=1.0):
 
 @pytest.mark.parametrize("m,n,k", [(256, 128, 64), (300, 70, 45), (13, 200, 130), (1024, 768, 256), (129, 129, 33)])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True), (True, False)])
-def test_gemm_fp16x3_all_layouts(ops, m, n, k, ta, tb):
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])          # library's choice, 128x128, 128x64, 64x64 workgroup tiles
+def test_gemm_fp16x3_all_layouts(ops, m, n, k, ta, tb, tile):
     a = rnd(m, k, seed=1); b = rnd(n, k, seed=2, scale=k ** -0.5)
     ref = a.double() @ b.double().t()
     A = (a.t().contiguous() if ta else a).cuda()
     Bm = (b.t().contiguous() if tb else b).cuda()
-    c = ops.gemm(A, Bm, m, n, k, trans_a=ta, trans_b=tb)
+    c = ops.gemm(A, Bm, m, n, k, trans_a=ta, trans_b=tb, tile=tile)
     assert rel_l2(c, ref) < 2e-6
     bias = rnd(n, seed=3); res = rnd(7, n, seed=4); msk = rnd(m, n, seed=5)
     c2 = ops.gemm(A, Bm, m, n, k, trans_a=ta, trans_b=tb, bias=bias.cuda(), relu=True, resid=res.cuda(), res_rows=7,
-                  mask=msk.cuda())
+                  mask=msk.cuda(), tile=tile)
     want = torch.relu(ref + bias.double()) + res.double()[torch.arange(m) % 7]
     want = torch.where(msk.double() > 0, want, torch.zeros_like(want))
     assert rel_l2(c2, want) < 2e-6
     for ks in (2, 5, 64):
         acc = torch.zeros(m, n, device="cuda")
-        ops.gemm(A, Bm, m, n, k, trans_a=ta, trans_b=tb, out=acc, ksplit=ks)
-        ops.gemm(A, Bm, m, n, k, trans_a=ta, trans_b=tb, out=acc, ksplit=ks)
+        ops.gemm(A, Bm, m, n, k, trans_a=ta, trans_b=tb, out=acc, ksplit=ks, tile=tile)
+        ops.gemm(A, Bm, m, n, k, trans_a=ta, trans_b=tb, out=acc, ksplit=ks, tile=tile)
         assert rel_l2(acc, 2 * ref) < 2e-6, ks
 
 
