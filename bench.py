@@ -349,7 +349,7 @@ def main():
         tr_e.use_graph = False
         with KernelTimer() as kt:
             for _ in range(args.profile_steps):
-                tr_e._fwd_bwd(x, y)
+                tr_e._fwd_bwd(x, y, overlap=False)    # (micro-batches one after the other: per-launch times undisturbed)
                 tr_e._adam()
         summ = kt.summary()
         for name, d in summ.items():
@@ -407,7 +407,7 @@ def main():
             "config": {"workload": f"unet_convlstm_attention base={base} seq_len={T} {H}x{W} 5->2, "
                                    f"per-GPU batch {B} ({_which_config(base, T, H, W)}), fwd+MSE+bwd+all-reduce+Adam",
                        "global_batch": gb, "seq_len": T, "parallelism": f"dp{world}",
-                       "hip_graph": not args.no_graph},
+                       "hip_graph": not args.no_graph, "micro_batches": tr._parts},
             "step_mfma_frac": round(value / world * fl / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
             "final_loss": final_loss,
             "fwd_samples_per_s": None if fwd_sps is None else round(fwd_sps, 1), "h2d": h2d,

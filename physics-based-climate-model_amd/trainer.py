@@ -10,7 +10,17 @@ Equivalent to one iteration of Lightning's automatic optimisation around ``train
 (main_final.py:556-561, 737-747) with ``optimizer.zero_grad(); loss.backward(); optimizer.step()``, but scheduled
 directly on the engine: flat parameter / gradient / moment buffers, one fused Adam launch, and (optionally) the whole
 device-side step recorded once into a hipGraph and replayed, which removes ~300 launches' worth of host time.
+
+Micro-batch overlap (``micro_batches=2``; chosen automatically for small workloads, see ``_auto_micro``).  At BASELINE
+config 2 a third of the step is the decoder and the ConvLSTM recurrence: B = 32 frames at 6x9 ... 48x72, chains of small
+launches that leave most of the 256 CUs empty, and nothing else in the step is independent of them.  Two HALVES of the
+batch are: the per-GPU batch is cut in two contiguous halves that run {forward, loss, backward} on two HIP streams
+(forked and joined inside the captured graph), each into its own flat gradient buffer; the halves share the packed
+weights, the two buffers are averaged before Adam (MSE is a mean over the batch and every layer of the model is
+per-sample, so the average of the halves' gradients IS the batch gradient: same arithmetic as gradient accumulation, up to
+fp32 summation order).  Measured +5 % samples/s at config 2 (tools/microbatch_probe.py); four parts lose.
 """
+import os
 from typing import Optional
 
 import torch
@@ -21,7 +31,7 @@ from ._lib import check, lib
 
 class HotPathTrainer:
     def __init__(self, model, lr: float = 5e-4, weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8,
-                 use_graph: bool = True, distributed: Optional[bool] = None):
+                 use_graph: bool = True, distributed: Optional[bool] = None, micro_batches: Optional[int] = None):
         self.model = model
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         dev = next(model.parameters()).device
@@ -30,9 +40,18 @@ class HotPathTrainer:
         self.device = dev
         self.flat = model._flat if model._flat is not None else model.flatten_parameters_()
         self.nt = model.n_flat_trainable
-        # flat gradient with the loss scalar behind it: one zero-fill launch clears both
-        self._gradbuf = torch.zeros(self.nt + 1, device=dev, dtype=torch.float32)
+        # flat gradient with the loss scalar behind it: one zero-fill launch clears both (and the second micro-batch's
+        # pair, which lives in the same allocation one 256-byte-aligned pitch further on)
+        self.micro = micro_batches          # None: decided per batch shape (_auto_micro); 1 or 2 otherwise
+        self._gpitch = (self.nt + 1 + 63) // 64 * 64
+        self._gradall = torch.zeros(2 * self._gpitch, device=dev, dtype=torch.float32)
+        self._gradbuf = self._gradall[:self.nt + 1]
+        self._gradbuf2 = self._gradall[self._gpitch:self._gpitch + self.nt + 1]
         self.grad = self._gradbuf[:self.nt]
+        self.grad2 = self._gradbuf2[:self.nt]
+        self.loss2 = self._gradbuf2[self.nt:]
+        self._side = torch.cuda.Stream(device=dev)   # second stream of the micro-batch overlap
+        self._parts = 1                     # micro-batches of the step being issued
         self.m = torch.zeros(self.nt, device=dev, dtype=torch.float32)
         self.v = torch.zeros(self.nt, device=dev, dtype=torch.float32)
         self.adam_state = torch.zeros(4, device=dev, dtype=torch.float32)   # device-side step counter + corrections
@@ -46,40 +65,102 @@ class HotPathTrainer:
         self._plans = []          # strong references: captured graphs hold raw pointers into these plans' arenas
         self.steps = 0
         self.keep_saved = False   # debugging / tests: keep the last forward's saved activations in ``self.saved``
+        #                           (one engine.Saved, or the list of the micro-batches' when the step ran two)
         self.saved = None
         self.bucket_exchange = True   # world > 1: two gradient buckets, the first exchanged beside the encoder backward
         self._mid = None
 
     # ------------------------------------------------------------------ pieces
-    def _fwd_bwd(self, x, y, phase=None):
+    def _auto_micro(self, x) -> int:
+        """Two micro-batches when the workload is small enough that its decoder / ConvLSTM launches leave the chip
+        mostly empty (BASELINE config 2: 32 x 6 frames of 48x72 at base 32); one for the larger configurations, whose
+        launches fill the chip on their own (configs 3 and 5), and for every other model."""
+        env = os.environ.get("CM_MICRO_BATCHES")
+        if self.micro is not None or env:
+            n = int(self.micro if self.micro is not None else env)
+            if n not in (1, 2):
+                raise ValueError("micro_batches must be 1 or 2")
+            if n == 2 and x.shape[0] % 2:
+                raise ValueError(f"micro_batches=2 needs an even batch, got {x.shape[0]}")
+            return n
+        from . import engine as _e
+        if type(self.model).__name__ != "AttUNetConvLSTM" or x.dim() != 5 or _e.OVERLAP_WGRAD or _e.OVERLAP_LSTM:
+            return 1
+        B, T, _, H, W = x.shape
+        base = getattr(self.model, "base", 0)
+        return 2 if (B % 2 == 0 and B >= 4 and float(B) * T * H * W * base * base < 2e9) else 1
+
+    def _run_parts(self, fn, overlap=True):
+        """fn(0) on the current stream, fn(1) beside it on the side stream (fork / join through events: works eagerly
+        and under graph capture); one after the other when ``overlap`` is off (autotuning passes)."""
+        if self._parts == 1:
+            fn(0)
+            return
+        if not overlap:
+            fn(0)
+            fn(1)
+            return
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            fn(1)
+        fn(0)
+        main.wait_stream(self._side)
+
+    def _fwd_bwd(self, x, y, phase=None, overlap=True):
         """phase None: the whole {zero, pack, forward, loss, backward}; "early": up to and including the decoder /
         ConvLSTM half of the backward (its gradient bucket final); "late": the encoder half (needs "early" first)."""
+        nt = self.nt
         if phase == "late":
-            p, pk, g, sv, st = self._mid
-            self.model._engine_backward_late(p, pk, g, sv, st)
+            def late(i):
+                p, pk, g, sv, st = self._mid[i]
+                self.model._engine_backward_late(p, pk, g, sv, st)
+            self._run_parts(late, overlap)
             self._mid = None
+            if self._parts == 2:
+                bb = self.model.bucket_boundary
+                self.grad[:bb].lerp_(self.grad2[:bb], 0.5)
             return
+        self._parts = self._auto_micro(x)
         p = self.model._param_dict()
-        g = self.model._views(self.grad)
-        check(lib.cm_zero(self._gradbuf.data_ptr(), (self.nt + 1) * 4, torch.cuda.current_stream().cuda_stream),
-              "zero")
+        gs = [self.model._views(self.grad), self.model._views(self.grad2)][:self._parts]
+        nz = (nt + 1) if self._parts == 1 else self._gpitch + nt + 1
+        check(lib.cm_zero(self._gradall.data_ptr(), nz * 4, torch.cuda.current_stream().cuda_stream), "zero")
         plan = engine.get_plan(p, None, False)
-        bplan = engine.get_plan(p, g, False)
-        if not any(q is plan for q in self._plans):
-            self._plans.append(plan)
-        if not any(q is bplan for q in self._plans):
-            self._plans.append(bplan)
+        for q in [plan] + [engine.get_plan(p, g, False) for g in gs]:
+            if not any(q is r for r in self._plans):
+                self._plans.append(q)
         pk = plan.pack()
-        _, sv = self.model._engine_forward(p, pk, x, save=True, head=False)
-        # output head + MSE + the head's backward: one pass over the last decoder activation
+        h = x.shape[0] // self._parts
+        losses = (self.loss, self.loss2)
+        mids = [None, None]
+        saved = [None, None]
         hw, hb = getattr(self.model, "_head_param_names", ("head.weight", "head.bias"))
-        dd1 = ops.head_mse_bwd(sv.d1, p[hw], p[hb], y, self.loss, g[hw], g[hb])
+
+        def part(i):
+            xi, yi, g = x[i * h:(i + 1) * h], y[i * h:(i + 1) * h], gs[i]
+            _, sv = self.model._engine_forward(p, pk, xi, save=True, head=False)
+            # output head + MSE + the head's backward: one pass over the last decoder activation
+            dd1 = ops.head_mse_bwd(sv.d1, p[hw], p[hb], yi, losses[i], g[hw], g[hb])
+            if self.keep_saved:
+                saved[i] = sv
+            if phase == "early":
+                mids[i] = (p, pk, g, sv, self.model._engine_backward_early(p, pk, g, sv, dd1))
+            else:
+                self.model._engine_backward(p, pk, g, sv, None, need_dx=False, dd1=dd1)
+        self._run_parts(part, overlap)
         if self.keep_saved:
-            self.saved = sv
+            self.saved = saved[0] if self._parts == 1 else saved
         if phase == "early":
-            self._mid = (p, pk, g, sv, self.model._engine_backward_early(p, pk, g, sv, dd1))
-            return
-        self.model._engine_backward(p, pk, g, sv, None, need_dx=False, dd1=dd1)
+            self._mid = mids
+        if self._parts == 2:
+            # each half's loss and gradients are means over ITS samples: the batch's are their averages (one launch over
+            # {gradients, loss}; a + (b - a) / 2)
+            if phase == "early":
+                bb = self.model.bucket_boundary
+                self._gradbuf[bb:].lerp_(self._gradbuf2[bb:], 0.5)
+            else:
+                self._gradbuf.lerp_(self._gradbuf2, 0.5)
 
     def _adam(self):
         b1, b2 = self.betas
@@ -204,8 +285,9 @@ class HotPathTrainer:
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            self._fwd_bwd(sx, sy)          # autotunes every call signature, learns which weight packs are used
-            self._fwd_bwd(sx, sy)          # builds the pruned pack table (cannot be built during capture)
+            # (micro-batches one after the other here: the autotuner's timings must not see the other stream)
+            self._fwd_bwd(sx, sy, overlap=False)   # autotunes every call signature, learns which weight packs are used
+            self._fwd_bwd(sx, sy, overlap=False)   # builds the pruned pack table (cannot be built during capture)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g1 = torch.cuda.CUDAGraph()

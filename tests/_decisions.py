@@ -19,7 +19,16 @@ def _mask(ctx):
 
 
 def hip_decisions(sv, delta=1e-5):
-    """sv: engine.Saved of one forward.  Returns oracle.Decisions keyed like the oracle's sites."""
+    """sv: engine.Saved of one forward -- or the list of the micro-batches' Saved objects (contiguous parts of the batch,
+    in order: HotPathTrainer.saved with micro_batches=2).  Returns oracle.Decisions keyed like the oracle's sites."""
+    if isinstance(sv, (list, tuple)):
+        parts = [hip_decisions(q, delta) for q in sv]
+        dec = oracle.Decisions(delta=delta)
+        for k in parts[0].amax:
+            dec.amax[k] = torch.cat([q.amax[k] for q in parts], 0)
+        for k in parts[0].pool:
+            dec.pool[k] = torch.cat([q.pool[k] for q in parts], 0)
+        return dec
     dec = oracle.Decisions(delta=delta)
     T = sv.T
     enc_prefix = ("enc1.", "enc2.conv.", "enc3.conv.", "enc4.conv.")

@@ -453,6 +453,41 @@ def test_trainer_checkpoint_resume(amd):
     assert cpu.param_groups[0]["lr"] == 5e-4
 
 
+# ----------------------------------------------------------------------------------------------- micro-batch overlap
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_micro_batch_overlap_equals_one_batch(amd, use_graph):
+    """HotPathTrainer(micro_batches=2): the batch's halves run on two streams into two gradient buffers that are
+    averaged before Adam.  Loss, every gradient and the parameters after three Adam steps equal the one-batch
+    schedule's to rounding (summation order), eagerly and through the captured graph; the automatic choice picks two
+    micro-batches at BASELINE config 2's workload and one at the larger configurations."""
+    from climate_amd.trainer import HotPathTrainer
+    in_ch, out_ch, base, T, B, H, W = 5, 2, 16, 3, 6, 16, 24
+    gen = torch.Generator("cpu").manual_seed(31)
+    x = torch.randn(B, T, in_ch, H, W, generator=gen).cuda(); y = torch.randn(B, out_ch, H, W, generator=gen).cuda()
+    x[1, :T - 1] = 0.0                                   # a left-padded window in the first half
+    one = HotPathTrainer(_make(amd, in_ch, out_ch, base, T), lr=5e-4, use_graph=use_graph, distributed=False,
+                         micro_batches=1)
+    two = HotPathTrainer(_make(amd, in_ch, out_ch, base, T), lr=5e-4, use_graph=use_graph, distributed=False,
+                         micro_batches=2)
+    for step in range(3):
+        l1, l2 = one.step(x, y).item(), two.step(x, y).item()
+        assert two._parts == 2 and one._parts == 1
+        assert abs(l1 - l2) < 2e-6 * abs(l1), (step, l1, l2)
+        g1, g2 = one.model._views(one.grad), two.model._views(two.grad)
+        for k in g1:
+            assert torch.isfinite(g2[k]).all(), k
+            assert rel_l2(g2[k], g1[k]) < 5e-5, (step, k, rel_l2(g2[k], g1[k]))
+    for (k, a), (_, b) in zip(one.model.state_dict().items(), two.model.state_dict().items()):
+        assert rel_l2(b, a) < 2e-5, k
+    with pytest.raises(ValueError):
+        HotPathTrainer(_make(amd, in_ch, out_ch, base, T), use_graph=False, distributed=False,
+                       micro_batches=2).step(x[:3], y[:3])
+    auto = HotPathTrainer(_make(amd, in_ch, out_ch, 32, 6), use_graph=False, distributed=False)
+    assert auto._auto_micro(torch.empty(32, 6, 5, 48, 72, device="meta")) == 2        # BASELINE config 2
+    assert auto._auto_micro(torch.empty(16, 6, 5, 192, 288, device="meta")) == 1      # config 5's grid
+    assert auto._auto_micro(torch.empty(3, 6, 5, 48, 72, device="meta")) == 1         # odd batch
+
+
 # ----------------------------------------------------------------------------------------------- determinism / overlap
 def test_run_twice_determinism(amd):
     """Split-K convolutions and all weight gradients accumulate with fp32 atomics, so two runs are not bit-identical;
