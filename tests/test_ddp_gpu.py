@@ -13,7 +13,7 @@ import oracle
 from conftest import rel_l2
 
 pytestmark = pytest.mark.gpu
-CFG = dict(in_ch=5, out_ch=2, base=8, T=3, B=4, H=16, W=24)
+CFG = dict(in_ch=5, out_ch=2, base=8, T=3, B=8, H=16, W=24)   # 4 per rank: each rank runs two micro-batches
 
 
 def _free_port():
