@@ -208,14 +208,30 @@ class CNNTransformer(_HipModule):
         dev = next(self.parameters()).device
         self.__dict__["_rng"] = torch.tensor([int(seed) & 0x7fffffff, int(counter)], dtype=torch.int32, device=dev)
 
-    def _engine_forward(self, p, pk, x, save=True, head=True):
+    def _engine_forward(self, p, pk, x, save=True, head=True, rng_snapshot=None):
         drop = None
         if self.training and self.dropout_p > 0.0:
-            rng = self._rng_state(x.device)
-            ops.rng_advance(rng)
-            # this call's snapshot: a later forward (gradient accumulation) must not change the masks of this backward
-            drop = (rng.clone(), self.dropout_p)
+            if rng_snapshot is None:
+                rng = self._rng_state(x.device)
+                ops.rng_advance(rng)
+                # this call's snapshot: a later forward (gradient accumulation) must not change the masks of this backward
+                rng_snapshot = rng.clone()
+            drop = (rng_snapshot, self.dropout_p)
         return forward(p, x, self.n_heads, save=save, head=head, drop=drop)
+
+    def _micro_prepare(self, device, parts: int):
+        """Per-micro-batch keyword arguments of ``_engine_forward`` for forwards that run CONCURRENTLY (the trainer's
+        micro-batch overlap): the dropout counter is advanced once per part here, on the caller's stream, and every part
+        gets its own {seed, counter} snapshot -- two forwards advancing the device counter from two streams would race
+        and could draw the same masks."""
+        if not (self.training and self.dropout_p > 0.0):
+            return [{} for _ in range(parts)]
+        rng = self._rng_state(device)
+        out = []
+        for _ in range(parts):
+            ops.rng_advance(rng)
+            out.append({"rng_snapshot": rng.clone()})
+        return out
 
     def _engine_backward(self, p, pk, g, sv, dpred, need_dx=False, dd1=None):
         return backward(p, g, sv, self.n_heads, dpred=dpred, dd_head=dd1, need_dx=need_dx)

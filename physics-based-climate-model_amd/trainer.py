@@ -72,9 +72,9 @@ class HotPathTrainer:
 
     # ------------------------------------------------------------------ pieces
     def _auto_micro(self, x) -> int:
-        """Two micro-batches when the workload is small enough that its decoder / ConvLSTM launches leave the chip
-        mostly empty (BASELINE config 2: 32 x 6 frames of 48x72 at base 32); one for the larger configurations, whose
-        launches fill the chip on their own (configs 3 and 5), and for every other model."""
+        """Two micro-batches when the workload is small enough that its launches leave the chip partly empty (BASELINE
+        config 2: 32 x 6 frames of 48x72 at base 32; config 4: the cnn_transformer at batch 64); one for the larger
+        configurations, whose launches fill the chip on their own (configs 3 and 5), and for every other model."""
         env = os.environ.get("CM_MICRO_BATCHES")
         if self.micro is not None or env:
             n = int(self.micro if self.micro is not None else env)
@@ -84,11 +84,17 @@ class HotPathTrainer:
                 raise ValueError(f"micro_batches=2 needs an even batch, got {x.shape[0]}")
             return n
         from . import engine as _e
-        if type(self.model).__name__ != "AttUNetConvLSTM" or x.dim() != 5 or _e.OVERLAP_WGRAD or _e.OVERLAP_LSTM:
+        B = x.shape[0]
+        if B % 2 or B < 4 or _e.OVERLAP_WGRAD or _e.OVERLAP_LSTM:
             return 1
-        B, T, _, H, W = x.shape
-        base = getattr(self.model, "base", 0)
-        return 2 if (B % 2 == 0 and B >= 4 and float(B) * T * H * W * base * base < 2e9) else 1
+        kind = type(self.model).__name__
+        if kind == "AttUNetConvLSTM" and x.dim() == 5:
+            _, T, _, H, W = x.shape
+            base = getattr(self.model, "base", 0)
+            return 2 if float(B) * T * H * W * base * base < 2e9 else 1
+        if kind == "CNNTransformer" and x.dim() == 4:     # BASELINE config 4 (batch 64, embed 256): +7 %
+            return 2 if float(B) * x.shape[2] * x.shape[3] * getattr(self.model, "embed_dim", 1 << 20) < 2.5e8 else 1
+        return 1
 
     def _run_parts(self, fn, overlap=True):
         """fn(0) on the current stream, fn(1) beside it on the side stream (fork / join through events: works eagerly
@@ -136,10 +142,13 @@ class HotPathTrainer:
         mids = [None, None]
         saved = [None, None]
         hw, hb = getattr(self.model, "_head_param_names", ("head.weight", "head.bias"))
+        # state that concurrent forwards must not share (the cnn_transformer's dropout counter): prepared here, in order
+        prep = getattr(self.model, "_micro_prepare", None)
+        kws = prep(x.device, self._parts) if (prep is not None and self._parts > 1) else [{}] * self._parts
 
         def part(i):
             xi, yi, g = x[i * h:(i + 1) * h], y[i * h:(i + 1) * h], gs[i]
-            _, sv = self.model._engine_forward(p, pk, xi, save=True, head=False)
+            _, sv = self.model._engine_forward(p, pk, xi, save=True, head=False, **kws[i])
             # output head + MSE + the head's backward: one pass over the last decoder activation
             dd1 = ops.head_mse_bwd(sv.d1, p[hw], p[hb], yi, losses[i], g[hw], g[hb])
             if self.keep_saved:

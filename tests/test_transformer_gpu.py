@@ -306,7 +306,7 @@ def test_cnn_transformer_dropout_through_graphed_trainer(ops):
     B, E, depth, H, mlp, S, p = 2, 32, 1, 4, 48, 216, 0.1
     m = CNNTransformer(5, 2, E, depth, H, mlp, dropout=p).cuda().train()
     m.reseed_dropout(5)
-    tr = HotPathTrainer(m, lr=5e-4, use_graph=True, distributed=False)
+    tr = HotPathTrainer(m, lr=5e-4, use_graph=True, distributed=False, micro_batches=1)   # one batch: one mask set
     tr.keep_saved = True
     from _decisions import transformer_relu_decisions
     gen = torch.Generator("cpu").manual_seed(8)
@@ -368,7 +368,7 @@ def test_cnn_transformer_config4_width_vs_oracle(ops):
     #   (2) the parameters after the step == torch.optim.Adam (float64) fed with the device's gradients.
     m2 = CNNTransformer(5, 2, 256, 2, 8, 256, dropout=0.0)
     m2.load_state_dict(P)
-    tr = HotPathTrainer(m2.cuda(), lr=5e-4, use_graph=True, distributed=False)
+    tr = HotPathTrainer(m2.cuda(), lr=5e-4, use_graph=True, distributed=False, micro_batches=1)
     names = [n for n, _ in m2.named_parameters()]
     pa = {k: P[k].double().clone().requires_grad_() for k in names}
     opt = torch.optim.Adam([pa[k] for k in names], lr=5e-4)
@@ -413,3 +413,59 @@ def test_cnn_transformer_config4_width_vs_oracle(ops):
             assert err < 1e-5, (k, step, err)
     print(f"cnn_transformer config-4 widths, 3 fused Adam steps: worst gradient rel-L2 {worst_g:.2e}, "
           f"worst parameter rel-L2 vs float64 Adam on the same gradients {worst_p:.2e}")
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_cnn_transformer_micro_batch_overlap(ops, use_graph):
+    """HotPathTrainer(micro_batches=2) on the cnn_transformer: without dropout the two-halves schedule reproduces the
+    one-batch loss, gradients and parameters (three Adam steps); with dropout every half draws its own masks from its
+    own counter value (prepared on the main stream before the fork: two forwards must never advance the device counter
+    concurrently), the counter moves by two per step, and the config-4 workload selects two micro-batches."""
+    from climate_amd.cnn_transformer import CNNTransformer
+    from climate_amd.trainer import HotPathTrainer
+    torch.manual_seed(3)
+    B, E, depth, H, mlp = 4, 64, 2, 4, 96
+    ref = CNNTransformer(5, 2, E, depth, H, mlp, dropout=0.0)
+    P = {k: v.clone() for k, v in ref.state_dict().items()}
+    gen = torch.Generator("cpu").manual_seed(9)
+    x = torch.randn(B, 5, 48, 72, generator=gen).cuda(); y = torch.randn(B, 2, 48, 72, generator=gen).cuda()
+    trs = []
+    for parts in (1, 2):
+        m = CNNTransformer(5, 2, E, depth, H, mlp, dropout=0.0)
+        m.load_state_dict(P)
+        trs.append(HotPathTrainer(m.cuda().train(), lr=5e-4, use_graph=use_graph, distributed=False, micro_batches=parts))
+    one, two = trs
+    for step in range(3):
+        l1, l2 = one.step(x, y).item(), two.step(x, y).item()
+        assert two._parts == 2
+        assert abs(l1 - l2) < 2e-6 * abs(l1), (step, l1, l2)
+        # (ReLU decisions of elements within rounding of zero may differ between the schedules: tolerance as the other
+        # schedule-to-schedule checks)
+        assert rel_l2(two.grad, one.grad) < 5e-5, (step, rel_l2(two.grad, one.grad))
+    # (parameters are not compared one by one: Adam's g / (|g| + eps) turns the rounding noise of gradients that are
+    # zero in exact arithmetic -- the key bias, to which the softmax is invariant -- into +-lr steps; the per-step loss and
+    # gradient checks above bound the trajectories instead, as in test_cnn_transformer_config4_width_vs_oracle)
+    for (k, a), (_, b) in zip(one.model.state_dict().items(), two.model.state_dict().items()):
+        if "in_proj_bias" not in k:
+            assert rel_l2(b, a) < 1e-4, k
+    # dropout on: two counter values per step, different masks in the two halves (identical halves => different losses)
+    md = CNNTransformer(5, 2, E, depth, H, mlp, dropout=0.3)
+    md.load_state_dict(P)
+    md = md.cuda().train()
+    md.reseed_dropout(11)
+    td = HotPathTrainer(md, lr=0.0, use_graph=use_graph, distributed=False, micro_batches=2)
+    xx = torch.cat([x[:2], x[:2]]); yy = torch.cat([y[:2], y[:2]])
+    prev = None
+    for step in range(3):
+        loss = td.step(xx, yy).item()
+        assert td._parts == 2 and loss == loss
+        seed, counter = md._rng.tolist()
+        # (the first graphed step also runs the capture's warm-up passes: only the per-step increment is fixed)
+        assert seed == 11 and (prev is None or counter == prev + 2), (step, counter, prev)
+        prev = counter
+        la, lb = td.loss.item(), td.loss2.item()            # (loss = their average; loss2 = the second half's own mean)
+        assert abs(lb - (2 * la - lb)) > 1e-6 * abs(la)     # first half's mean = 2*loss - loss2: the halves differ
+    big = CNNTransformer(5, 2, 256, 1, 8, 256).cuda().train()
+    auto = HotPathTrainer(big, use_graph=False, distributed=False)
+    assert auto._auto_micro(torch.empty(64, 5, 48, 72, device="meta")) == 2           # BASELINE config 4
+    assert auto._auto_micro(torch.empty(512, 5, 48, 72, device="meta")) == 1
