@@ -193,7 +193,7 @@ def bench_cnn_transformer(args):
         tr.use_graph = False
         with KernelTimer() as kt:
             for _ in range(args.profile_steps):
-                tr._fwd_bwd(sx, sy)
+                tr._fwd_bwd(sx, sy, overlap=False)    # (micro-batches one after the other: per-launch times undisturbed)
                 tr._adam()
         for name, d in kt.summary().items():
             kernels[name] = {"calls_per_step": d["calls"] / args.profile_steps,
@@ -236,7 +236,8 @@ def bench_cnn_transformer(args):
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"cnn_transformer embed_dim=256 depth=6 n_heads=8 mlp_dim={cfg.model.mlp_dim} dropout="
                                f"{cfg.model.dropout} (training mode) 48x72 5->2, batch {B} (BASELINE.json configs[3]), "
-                               "fwd+MSE+bwd+Adam", "global_batch": B, "parallelism": "dp1", "hip_graph": not args.no_graph},
+                               "fwd+MSE+bwd+Adam", "global_batch": B, "parallelism": "dp1", "hip_graph": not args.no_graph,
+                       "micro_batches": tr._parts},
         "final_loss": loss.item(), "roofline": roof, "cpu_baseline": cpu, "kernels": kernels}))
 
 
