@@ -387,6 +387,16 @@ def main():
             roof.update({"traffic": load_pmc_traffic(name), "mfma_busy": load_pmc_mfma(name),
                          "launches_per_step": c["calls"] / args.profile_steps,
                          "avg_launch_us": round(c["ms"] * 1e3 / c["calls"], 2)})
+            if tr._parts > 1:
+                # the timed region runs the batch as tr._parts micro-batches on as many streams; this pass (like rocprofv3's
+                # kernel trace, which serialises dispatches) times every launch ALONE at the micro-batch's shape
+                iso = sum(d["ms"] for d in summ.values()) / args.profile_steps
+                roof["co_run"] = {"streams": tr._parts, "sum_of_isolated_launches_ms": round(iso, 4),
+                                  "timed_step_ms": round(dt / args.steps * 1e3, 4),
+                                  "overlap_factor": round(iso / (dt / args.steps * 1e3), 3),
+                                  "note": "achieved / frac are per launch in isolation at the micro-batch shape (half the "
+                                          "batch); in the timed region two such launch streams run side by side and the "
+                                          "step takes 1/overlap_factor of their summed durations"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
