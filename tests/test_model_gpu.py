@@ -484,7 +484,11 @@ def test_micro_batch_overlap_equals_one_batch(amd, use_graph):
                        micro_batches=2).step(x[:3], y[:3])
     auto = HotPathTrainer(_make(amd, in_ch, out_ch, 32, 6), use_graph=False, distributed=False)
     assert auto._auto_micro(torch.empty(32, 6, 5, 48, 72, device="meta")) == 2        # BASELINE config 2
-    assert auto._auto_micro(torch.empty(16, 6, 5, 192, 288, device="meta")) == 1      # config 5's grid
+    assert auto._auto_micro(torch.empty(32, 12, 5, 48, 72, device="meta")) == 2
+    auto.model.base = 64
+    assert auto._auto_micro(torch.empty(32, 12, 5, 48, 72, device="meta")) == 2       # config 3
+    assert auto._auto_micro(torch.empty(16, 6, 5, 192, 288, device="meta")) == 1      # config 5
+    auto.model.base = 32
     assert auto._auto_micro(torch.empty(3, 6, 5, 48, 72, device="meta")) == 1         # odd batch
 
 
