@@ -150,7 +150,9 @@ def self_launch(args, argv):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out, _ = procs[0].communicate()
     rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    # relay rank 0's JSON line; anything else a backend printed on stdout (gloo's connection banner) goes to stderr
+    for line in out.decode().splitlines():
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     raise SystemExit(max(abs(rc) for rc in rcs))
 
