@@ -218,6 +218,18 @@ int cm_lstm_gates_bwd(float* gates, long long sg, const float* c_prev, long long
                       long long scc, const float* dh_a, long long sa, const float* dh_b, long long sb, float* dc,
                       int first, int b, int ch, int hw, cm_stream stream);
 
+/* The same two stages fed by a "partial slices" recurrent projection (cm_conv3x3_h3 config bit 29: the reduction shares
+ * of the h-projection / its data gradient are STORED as nparts slices instead of being added with atomics -- the
+ * recurrence is a chain of small launches whose cost is latency, and the atomics were half of it):
+ * forward: pre-activation = gates + sum_z parts[z] (slices zs apart, sample stride sp, [b,4ch,hw] each);
+ * backward: dh = dh_a + sum_z dh_parts[z] (slices zb apart, sample stride sb, [b,ch,hw] each).  Fixed summation order. */
+int cm_lstm_gates_fwd_parts(float* gates, long long sg, const float* parts, long long sp, long long zs, int nparts,
+                            const float* c_prev, long long scp, float* c_out, long long sco, float* h_out,
+                            long long sho, int b, int ch, int hw, cm_stream stream);
+int cm_lstm_gates_bwd_parts(float* gates, long long sg, const float* c_prev, long long scp, const float* c_cur,
+                            long long scc, const float* dh_a, long long sa, const float* dh_parts, long long sb,
+                            long long zb, int nparts, float* dc, int first, int b, int ch, int hw, cm_stream stream);
+
 /* ---- head + loss ------------------------------------------------------------------------------------------- *
  * nn.Conv2d(base, out_ch, 1): src/unet_convlstm_attention.py:56,104.  nn.MSELoss(): main_final.py:544,559.       */
 int cm_head_fwd(const float* x, long long sx, const float* w, const float* b, float* pred, int n, int c, int oc,

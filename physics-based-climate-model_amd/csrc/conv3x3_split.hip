@@ -41,6 +41,8 @@ struct SplitArgs {
   const float* winv;      // fp16x3: device scalar, 1 / (power-of-two scale the packed weights carry)
   unsigned* be_out;       // fp16x3, optional: per-sample biased exponent of max|input| (atomic max), see cm_conv3x3_h3
   long long be_stride;
+  long long zstride;      // > 0 ("partial slices"): reduction share blockIdx.z STORES its partial sums into slice z of a
+                          // [ksplit][N] stack (out + z * zstride) -- no zero fill, no atomics; the consumer adds the slices
 };
 
 // Workgroups with one 32x32 tile per wave sit 2 registers above the 3-waves-per-SIMD allocation (170 of 168): ask for
@@ -442,10 +444,10 @@ __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void c
         for (int r = 0; r < 16; ++r) {
           const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
           if (co < a.Cout) {
-            if (a.ksplit > 1)
+            if (a.ksplit > 1 && a.zstride == 0)
               unsafeAtomicAdd(a.out + obase[p] + (long long)co * HW, acc[m][p][r]);
             else
-              a.out[obase[p] + (long long)co * HW] = acc[m][p][r];
+              a.out[obase[p] + (long long)co * HW + (long long)blockIdx.z * a.zstride] = acc[m][p][r];
           }
         }
       }
@@ -590,9 +592,11 @@ int launch_s(const SplitArgs& a0, hipStream_t st) {
   SplitArgs a = a0;
   a.tiles_x = cdiv(a.W, c.tw);
   a.tiles_y = cdiv(a.H, c.th);
+  // partial slices: the caller reads exactly ksplit slices, each of which must own >= 1 k-step
+  if (a.zstride > 0 && (a.ksplit < 2 || a.ksplit > a.nsteps || a.nsteps % a.ksplit != 0)) return -22;
   if (a.ksplit > a.nsteps) a.ksplit = a.nsteps;
   if (a.ksplit < 1) a.ksplit = 1;
-  if (a.ksplit > 1 && !a.prezeroed) {
+  if (a.ksplit > 1 && !a.prezeroed && a.zstride == 0) {
     const long long per = (long long)a.Cout * a.H * a.W;
     const long long zb = ((long long)a.N * per + 255) / 256;
     zero_out_split_kernel<<<(int)(zb > 2048 ? 2048 : zb), 256, 0, st>>>(a.out, a.sto, a.N, per);
@@ -702,7 +706,7 @@ int cm_conv3x3_split(const float* in0, long long st0, int c0, const float* in1, 
   if (a.ksplit > 1 && resid == out) return -22;   // the in-place residual would be zeroed
   a.tiles_x = a.tiles_y = 0;
   a.winv = nullptr;
-  a.be_out = nullptr; a.be_stride = 0;
+  a.be_out = nullptr; a.be_stride = 0; a.zstride = 0;
   if (!offsets_fit_32bit(a)) return -22;
   return c1 > 0 ? dispatch_s<true, 3>(config, a, (hipStream_t)stream) : dispatch_s<false, 3>(config, a, (hipStream_t)stream);
 }
@@ -711,7 +715,10 @@ int cm_conv3x3_split(const float* in0, long long st0, int c0, const float* in1, 
  * config encoding; wps / wscale_inv from cm_pack_conv3x3_h3_batch.  Input scaling is internal (running maximum).
  * sample_be (optional, [n] entries be_stride apart, zeroed by the caller): the kernel raises entry i to the biased exponent
  * of max |input of sample i| over both input tensors (atomic max over workgroups) -- the per-sample magnitudes the
- * fp16x3 weight gradient (cm_wgrad3x3_h3) needs, obtained for free from the launch that reads the same tensor. */
+ * fp16x3 weight gradient (cm_wgrad3x3_h3) needs, obtained for free from the launch that reads the same tensor.
+ * config bit 29 ("partial slices", needs a reduction split k >= 2 that divides the 16-channel k-steps, no resid): `out` is
+ * a [k][n] stack of slices st_out apart; reduction share z STORES its partial sums into slice z (bias in slice 0) -- no
+ * zero fill, no atomics, a fixed summation order; the consumer adds the slices (cm_lstm_gates_fwd_parts / _bwd_parts). */
 int cm_conv3x3_h3(const float* in0, long long st0, int c0, const float* in1, long long st1, int c1, const void* wps,
                   const float* wscale_inv, const float* bias, const float* resid, long long st_resid, float* out,
                   long long st_out, unsigned* sample_be, long long be_stride, int n, int h, int w, int cout, int config,
@@ -727,9 +734,13 @@ int cm_conv3x3_h3(const float* in0, long long st0, int c0, const float* in1, lon
   a.nsteps = (c0 + c1 + SKC - 1) / SKC;
   a.prezeroed = (config >> 30) & 1;
   config &= ~(1 << 30);
+  const bool slices = (config >> 29) & 1;    // bit 29: partial slices, `out` = [ksplit][n] stack, st_out apart
+  config &= ~(1 << 29);
   a.ksplit = config >> 8;
   config &= 0xff;
   if (a.ksplit > 1 && resid == out) return -22;
+  if (slices && resid) return -22;
+  a.zstride = slices ? (long long)n * st_out : 0;
   a.tiles_x = a.tiles_y = 0;
   a.winv = wscale_inv;
   a.be_out = sample_be; a.be_stride = be_stride;

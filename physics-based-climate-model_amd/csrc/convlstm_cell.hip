@@ -11,7 +11,10 @@
 
 namespace {
 
-__global__ void lstm_gates_fwd_kernel(float* __restrict__ gates, long long sg, const float* __restrict__ c_prev,
+// parts (nullable): nparts partial sums of the recurrent projection ([nparts][B][4 Ch][HW] slices, zs apart, sample stride
+// sp: what a "partial slices" cm_conv3x3_h3 launch stores), added to the pre-activations in slice order
+__global__ void lstm_gates_fwd_kernel(float* __restrict__ gates, long long sg, const float* __restrict__ parts,
+                                      long long sp, long long zs, int nparts, const float* __restrict__ c_prev,
                                       long long scp, float* __restrict__ c_out, long long sco,
                                       float* __restrict__ h_out, long long sho, int B, int Ch, int HW) {
   const long long per = (long long)Ch * HW, total = (long long)B * per;
@@ -19,10 +22,15 @@ __global__ void lstm_gates_fwd_kernel(float* __restrict__ gates, long long sg, c
        idx += (long long)gridDim.x * blockDim.x) {
     const long long b = idx / per, r = idx % per;
     float* gp = gates + b * sg + r;
-    const float i = sigmoid_acc(gp[0]);
-    const float f = sigmoid_acc(gp[per]);
-    const float o = sigmoid_acc(gp[2 * per]);
-    const float g = tanhf(gp[3 * per]);
+    float pi = gp[0], pf = gp[per], po = gp[2 * per], pg = gp[3 * per];
+    for (int z = 0; z < nparts; ++z) {
+      const float* pp = parts + z * zs + b * sp + r;
+      pi += pp[0]; pf += pp[per]; po += pp[2 * per]; pg += pp[3 * per];
+    }
+    const float i = sigmoid_acc(pi);
+    const float f = sigmoid_acc(pf);
+    const float o = sigmoid_acc(po);
+    const float g = tanhf(pg);
     const float cp = c_prev ? c_prev[b * scp + r] : 0.f;
     const float cn = f * cp + i * g;
     gp[0] = i; gp[per] = f; gp[2 * per] = o; gp[3 * per] = g;
@@ -32,10 +40,12 @@ __global__ void lstm_gates_fwd_kernel(float* __restrict__ gates, long long sg, c
 }
 
 // dc buffer: in = dL/dc_t carried from step t+1 (ignored when first != 0), out = dL/dc_{t-1}
+// dh_b: nb >= 1 slices zb apart (the recurrent data gradient as partial sums), added in slice order
 __global__ void lstm_gates_bwd_kernel(float* __restrict__ gates, long long sg, const float* __restrict__ c_prev,
                                       long long scp, const float* __restrict__ c_cur, long long scc,
                                       const float* __restrict__ dh_a, long long sa, const float* __restrict__ dh_b,
-                                      long long sb, float* __restrict__ dc, int first, int B, int Ch, int HW) {
+                                      long long sb, long long zb, int nb, float* __restrict__ dc, int first, int B,
+                                      int Ch, int HW) {
   const long long per = (long long)Ch * HW, total = (long long)B * per;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
@@ -44,7 +54,8 @@ __global__ void lstm_gates_bwd_kernel(float* __restrict__ gates, long long sg, c
     const float i = gp[0], f = gp[per], o = gp[2 * per], g = gp[3 * per];
     float dh = 0.f;
     if (dh_a) dh += dh_a[b * sa + r];
-    if (dh_b) dh += dh_b[b * sb + r];
+    if (dh_b)
+      for (int z = 0; z < nb; ++z) dh += dh_b[z * zb + b * sb + r];
     const float tc = tanhf(c_cur[b * scc + r]);
     const float cp = c_prev ? c_prev[b * scp + r] : 0.f;
     const float dct = (first ? 0.f : dc[idx]) + dh * o * (1.f - tc * tc);
@@ -70,7 +81,17 @@ int cm_lstm_gates_fwd(float* gates, long long sg, const float* c_prev, long long
                       float* h_out, long long sho, int b, int ch, int hw, cm_stream stream) {
   if (b <= 0 || ch <= 0 || hw <= 0) return -22;
   lstm_gates_fwd_kernel<<<grid_for((long long)b * ch * hw, 256), 256, 0, (hipStream_t)stream>>>(
-      gates, sg, c_prev, scp, c_out, sco, h_out, sho, b, ch, hw);
+      gates, sg, nullptr, 0, 0, 0, c_prev, scp, c_out, sco, h_out, sho, b, ch, hw);
+  CM_CHECK_LAUNCH();
+  return 0;
+}
+
+int cm_lstm_gates_fwd_parts(float* gates, long long sg, const float* parts, long long sp, long long zs, int nparts,
+                            const float* c_prev, long long scp, float* c_out, long long sco, float* h_out,
+                            long long sho, int b, int ch, int hw, cm_stream stream) {
+  if (b <= 0 || ch <= 0 || hw <= 0 || nparts < 0 || (nparts > 0 && !parts)) return -22;
+  lstm_gates_fwd_kernel<<<grid_for((long long)b * ch * hw, 256), 256, 0, (hipStream_t)stream>>>(
+      gates, sg, parts, sp, zs, nparts, c_prev, scp, c_out, sco, h_out, sho, b, ch, hw);
   CM_CHECK_LAUNCH();
   return 0;
 }
@@ -80,7 +101,17 @@ int cm_lstm_gates_bwd(float* gates, long long sg, const float* c_prev, long long
                       int first, int b, int ch, int hw, cm_stream stream) {
   if (b <= 0 || ch <= 0 || hw <= 0) return -22;
   lstm_gates_bwd_kernel<<<grid_for((long long)b * ch * hw, 256), 256, 0, (hipStream_t)stream>>>(
-      gates, sg, c_prev, scp, c_cur, scc, dh_a, sa, dh_b, sb, dc, first, b, ch, hw);
+      gates, sg, c_prev, scp, c_cur, scc, dh_a, sa, dh_b, sb, 0, 1, dc, first, b, ch, hw);
+  CM_CHECK_LAUNCH();
+  return 0;
+}
+
+int cm_lstm_gates_bwd_parts(float* gates, long long sg, const float* c_prev, long long scp, const float* c_cur,
+                            long long scc, const float* dh_a, long long sa, const float* dh_parts, long long sb,
+                            long long zb, int nparts, float* dc, int first, int b, int ch, int hw, cm_stream stream) {
+  if (b <= 0 || ch <= 0 || hw <= 0 || nparts < 1 || !dh_parts) return -22;
+  lstm_gates_bwd_kernel<<<grid_for((long long)b * ch * hw, 256), 256, 0, (hipStream_t)stream>>>(
+      gates, sg, c_prev, scp, c_cur, scc, dh_a, sa, dh_parts, sb, zb, nparts, dc, first, b, ch, hw);
   CM_CHECK_LAUNCH();
   return 0;
 }

@@ -56,6 +56,12 @@ USE_SPLIT = NUMERICS == "bf16x6"
 USE_H3 = NUMERICS == "fp16x3"
 
 
+# The ConvLSTM recurrence is a serial chain of small launches (B samples at H/8 x W/8): its h-projection and the
+# data gradient of it run as "partial slices" launches (reduction shares stored, not added with atomics) whose slices the
+# pointwise gate kernels add while they read their other operands.  CM_LSTM_PARTS=0 restores the atomic form.
+PARTIAL_SLICES = os.environ.get("CM_LSTM_PARTS", "1") != "0"
+
+
 class _Packs:
     """Both operand forms of the packed 3x3 weights; ``conv(key, ...)`` lets the tuner choose the kernel family."""
 
@@ -73,6 +79,16 @@ class _Packs:
         # (-1 = untuned fallback under graph capture, which runs the fp32-MFMA family)
         self.uses_fp32[key] = self.uses_fp32.get(key, False) or ops.LAST_CONV_CONFIG < ops.SPLIT_BASE
         return out
+
+    def conv_parts(self, key, x0, cout, parts=None, be_out=None):
+        """The same conv as k stored partial sums (ops.conv3x3_parts) -- or None when this weight has no fp16x3 operand
+        or the reduction is too short; the caller then uses ``conv``."""
+        if not PARTIAL_SLICES or key not in self.pkh:
+            return None
+        res = ops.conv3x3_parts(x0, cout, self.pkh[key], self.winv[key], parts=parts, be_out=be_out)
+        if res is not None:
+            self.uses_fp32.setdefault(key, False)
+        return res
 
 
 class Plan:
@@ -439,15 +455,21 @@ def convlstm_fwd(p: Params, pk, s4: Tensor, B: int, T: int, save: bool = True, b
     hprev = _zeros(B, T, ch, h8, w8, device=dev)             # hprev[:, t] = h_{t-1}; slot 0 stays 0
     call = torch.empty(B, T, ch, h8, w8, device=dev, dtype=torch.float32)
     bott = torch.empty(B, ch, h8, w8, device=dev, dtype=torch.float32)
+    pbuf = None                     # slice stack of the partial-slices form, reused by every step
     for t in range(T):
+        parts = None
         if t > 0:
             # (slot t of every sample's row of the [B, T] table: first entry t, stride T)
             be_t = None if be[1] is None else ops.SampleExponents(be[1].t[t:], T)
-            pk.conv("lstm.h/f", hprev[:, t], 4 * ch, resid=gx[:, t], out=gx[:, t], be_out=be_t)
+            parts = pk.conv_parts("lstm.h/f", hprev[:, t], 4 * ch, parts=pbuf, be_out=be_t)
+            if parts is not None:
+                pbuf = parts[0]
+            else:
+                pk.conv("lstm.h/f", hprev[:, t], 4 * ch, resid=gx[:, t], out=gx[:, t], be_out=be_t)
             if be_t is not None:
                 be[1].valid = be_t.valid and (t == 1 or be[1].valid)
         ops.lstm_gates_fwd(gx[:, t], call[:, t - 1] if t > 0 else None, call[:, t],
-                           hprev[:, t + 1] if t + 1 < T else bott)
+                           hprev[:, t + 1] if t + 1 < T else bott, parts=parts)
     ctx = None
     if save:
         ctx = _LstmCtx()
@@ -471,8 +493,10 @@ def convlstm_bwd(p: Params, pk, g: Params, gw: Params, ss, ctx: _LstmCtx, dbott:
     dev = gx.device
     dc = torch.empty(B, ch, h8, w8, device=dev, dtype=torch.float32)
     dhrec = None
-    # the recurrent data gradients are tiny K-split launches: one zero fill for all T-1 outputs instead of one each
-    dh_rec_all = _zeros(max(T - 1, 1), B, ch, h8, w8, device=dev)
+    # the recurrent data gradients are tiny K-split launches: stored partial slices (no fill at all), or -- atomic form --
+    # one zero fill for all T-1 outputs instead of one each
+    dh_rec_all = None
+    pbuf = None
     if before_chain is not None:
         before_chain()
     for t in range(T - 1, -1, -1):
@@ -487,7 +511,13 @@ def convlstm_bwd(p: Params, pk, g: Params, gw: Params, ss, ctx: _LstmCtx, dbott:
         # dh_t = external part + recurrent part (either may be absent); dc carries dL/dc_t
         ops.lstm_gates_bwd(gx[:, t], call[:, t - 1] if t > 0 else None, call[:, t], ext, dhrec, dc, first=(t == T - 1))
         if t > 0:
-            dhrec = pk.conv("lstm.h/d", gx[:, t], ch, out=dh_rec_all[t - 1], out_zeroed=True)
+            dhrec = pk.conv_parts("lstm.h/d", gx[:, t], ch, parts=pbuf) if dh_rec_all is None else None
+            if dhrec is not None:
+                pbuf = dhrec[0]
+            else:
+                if dh_rec_all is None:
+                    dh_rec_all = _zeros(max(T - 1, 1), B, ch, h8, w8, device=dev)
+                dhrec = pk.conv("lstm.h/d", gx[:, t], ch, out=dh_rec_all[t - 1], out_zeroed=True)
     dA = gx.view(B * T, 4 * ch, h8, w8)            # now holds d(pre-activations) for every (b, t)
     gl = gw["convlstm.cell.conv.weight"]
 

@@ -246,6 +246,42 @@ def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1, w
     return out
 
 
+PART_SLICES = (2, 4, 8)      # reduction splits the partial-slices form of a conv may use
+
+
+def conv3x3_parts(x0, cout, wph, winv, bias=None, parts=None, config=-1, be_out=None):
+    """"Partial slices" form of the fp16x3 conv for launches that are too small to fill the chip (the ConvLSTM's
+    recurrent projection and its data gradient): the reduction is split k ways over blockIdx.z and share z STORES its
+    partial sums into slice z of ``parts`` [max(PART_SLICES), N, cout, H, W] -- no zero fill, no atomics (they were half
+    of such a launch's time), a fixed summation order.  Returns (parts, k): the consumer adds the first k slices
+    (lstm_gates_fwd / lstm_gates_bwd with ``parts``).  ``bias`` lands in slice 0; ``be_out`` as in conv3x3 (every share
+    posts the maxima of the channels it read).  Returns None when the reduction has
+    fewer than two 16-channel k-steps (the caller uses conv3x3)."""
+    n, c0, h, w = x0.shape
+    nsteps = (c0 + 15) // 16
+    ks = [k for k in PART_SLICES if nsteps % k == 0 and k <= nsteps]
+    if not ks or wph is None:
+        return None
+    if x0.stride(3) != 1 or x0.stride(2) != w or x0.stride(1) != h * w:
+        raise RuntimeError("conv3x3_parts needs dense HxW planes with channel stride H*W")
+    if parts is None:
+        parts = torch.empty(max(PART_SLICES), n, cout, h, w, device=x0.device, dtype=torch.float32)
+    if parts.shape[0] < max(ks) or tuple(parts.shape[1:]) != (n, cout, h, w) or not parts.is_contiguous():
+        raise RuntimeError("conv3x3_parts: parts must be a contiguous [>= k, N, cout, H, W] stack")
+
+    def call(cfg, dst, be=None):
+        return lib.cm_conv3x3_h3(_p(x0), x0.stride(0), c0, None, 0, 0, _p(wph), _p(winv), _p(bias), None, 0, _p(dst),
+                                 dst.stride(1), None if be is None else _p_any(be.t), 0 if be is None else be.stride,
+                                 n, h, w, cout, (cfg - H3_BASE) | (1 << 29), _stream())
+    if config < 0:
+        cands = [H3_BASE + c + (k << 8) for c in range(lib.cm_conv3x3_split_num_configs()) for k in ks]
+        config = _pick(("conv3x3p", n, h, w, c0, cout), cands, lambda cfg: call(cfg, parts), H3_BASE + (ks[0] << 8))
+    check(call(config, parts, be_out), "conv3x3_h3 (partial slices)")
+    if be_out is not None:
+        be_out.valid = True
+    return parts, (config - H3_BASE) >> 8
+
+
 def pack_conv3x3_split(w, c_off=0, cin=None, dgrad=False):
     """bf16x6 operand form of a 3x3 weight (single-job use of the batched packer; the engine batches all jobs)."""
     cout, cin_total = w.shape[0], w.shape[1]
@@ -543,17 +579,32 @@ def convT2x2_bwd(x, w, dy, dw, db):
 
 
 # ----------------------------------------------------------------------------------------------------- lstm / head
-def lstm_gates_fwd(gates, c_prev, c_out, h_out):
+def lstm_gates_fwd(gates, c_prev, c_out, h_out, parts=None):
+    """parts = (stack [>= k, B, 4 ch, h, w], k) from conv3x3_parts: the recurrent projection as k partial sums."""
     b, ch4, h, w = gates.shape
     ch = ch4 // 4
+    if parts is not None:
+        pt, k = parts
+        check(lib.cm_lstm_gates_fwd_parts(_p(gates), gates.stride(0), _p(pt), pt.stride(1), pt.stride(0), k, _p(c_prev),
+                                          0 if c_prev is None else c_prev.stride(0), _p(c_out), c_out.stride(0),
+                                          _p(h_out), h_out.stride(0), b, ch, h * w, _stream()), "lstm_fwd_parts")
+        return
     check(lib.cm_lstm_gates_fwd(_p(gates), gates.stride(0), _p(c_prev), 0 if c_prev is None else c_prev.stride(0),
                                 _p(c_out), c_out.stride(0), _p(h_out), h_out.stride(0), b, ch, h * w, _stream()),
           "lstm_fwd")
 
 
 def lstm_gates_bwd(gates, c_prev, c_cur, dh_a, dh_b, dc, first):
+    """dh_b: a tensor [B, ch, h, w], None, or (stack [>= k, B, ch, h, w], k) from conv3x3_parts."""
     b, ch4, h, w = gates.shape
     ch = ch4 // 4
+    if isinstance(dh_b, tuple):
+        pt, k = dh_b
+        check(lib.cm_lstm_gates_bwd_parts(_p(gates), gates.stride(0), _p(c_prev), 0 if c_prev is None else c_prev.stride(0),
+                                          _p(c_cur), c_cur.stride(0), _p(dh_a), 0 if dh_a is None else dh_a.stride(0),
+                                          _p(pt), pt.stride(1), pt.stride(0), k, _p(_contig(dc)), int(first), b, ch, h * w,
+                                          _stream()), "lstm_bwd_parts")
+        return
     check(lib.cm_lstm_gates_bwd(_p(gates), gates.stride(0), _p(c_prev), 0 if c_prev is None else c_prev.stride(0),
                                 _p(c_cur), c_cur.stride(0), _p(dh_a), 0 if dh_a is None else dh_a.stride(0), _p(dh_b),
                                 0 if dh_b is None else dh_b.stride(0), _p(_contig(dc)), int(first), b, ch, h * w,

@@ -45,6 +45,15 @@ def _lstm_bwd_bytes(a):    # (gates, sg, c_prev, scp, c_cur, scc, dh_a, sa, dh_b
     return 4.0 * a[12] * a[13] * a[14] * (reads + 5)
 
 
+def _lstm_fwd_parts_bytes(a):   # (gates, sg, parts, sp, zs, nparts, c_prev, scp, c_out, sco, h_out, sho, b, ch, hw, stream)
+    return 4.0 * a[12] * a[13] * a[14] * (4 + 4 * a[5] + (1 if a[6] else 0) + 4 + 2)
+
+
+def _lstm_bwd_parts_bytes(a):   # (gates, sg, c_prev, scp, c_cur, scc, dh_a, sa, dh_parts, sb, zb, nparts, dc, first, b, ch, hw, stream)
+    reads = 4 + (1 if a[2] else 0) + 1 + (1 if a[6] else 0) + a[11] + (0 if a[13] else 1)
+    return 4.0 * a[14] * a[15] * a[16] * (reads + 5)
+
+
 def _wgrad_h3_flops(a):    # cm_wgrad3x3_h3(x0, sx0, c0, x1, sx1, c1, dy, sdy, be_x, be_y, g, ctot, c_off, n, h, w, cout, config, stream)
     return _wgrad_flops(a[:8] + a[10:])
 
@@ -72,6 +81,8 @@ MODELS = {
     "cm_wgrad3x3_split": (_wgrad_flops, _wgrad_bytes),  # same argument positions; ALGORITHMIC flops
     "cm_lstm_gates_fwd": (None, _lstm_fwd_bytes),
     "cm_lstm_gates_bwd": (None, _lstm_bwd_bytes),
+    "cm_lstm_gates_fwd_parts": (None, _lstm_fwd_parts_bytes),
+    "cm_lstm_gates_bwd_parts": (None, _lstm_bwd_parts_bytes),
 }
 
 

@@ -476,7 +476,9 @@ def test_micro_batch_overlap_equals_one_batch(amd, use_graph):
         g1, g2 = one.model._views(one.grad), two.model._views(two.grad)
         for k in g1:
             assert torch.isfinite(g2[k]).all(), k
-            assert rel_l2(g2[k], g1[k]) < 5e-5, (step, k, rel_l2(g2[k], g1[k]))
+            # (TOL, not rounding level: gradients that cancel to ~1e-7 of their terms -- GroupNorm-invariant directions --
+            # move by several 1e-5 with the order of the float atomics alone, see test_run_twice_determinism)
+            assert rel_l2(g2[k], g1[k]) < TOL, (step, k, rel_l2(g2[k], g1[k]))
     for (k, a), (_, b) in zip(one.model.state_dict().items(), two.model.state_dict().items()):
         assert rel_l2(b, a) < 2e-5, k
     with pytest.raises(ValueError):

@@ -470,6 +470,56 @@ def test_lstm_gates(ops):
     assert rel_l2(gates, pd.grad) < TOL and rel_l2(dc, cpd.grad) < TOL
 
 
+def test_conv_partial_slices_and_lstm_gates_parts(ops):
+    """The ConvLSTM recurrence's launch form: cm_conv3x3_h3 with config bit 29 STORES its reduction shares as slices
+    (no zero fill, no atomics); the gate kernels add them while reading (cm_lstm_gates_fwd_parts / _bwd_parts).
+    Slices must sum to the convolution for every applicable split and tile configuration; the fused sums must equal the
+    unfused stages; a split that does not divide the k-steps is refused; per-sample exponents are still published."""
+    from climate_amd._lib import lib
+    b, ch, cx, h, w = 4, 32, 64, 6, 9                    # recurrent projection ch -> 4 ch, non-dense sample stride
+    hfull = rnd(b, 3, cx, h, w, seed=60)
+    hx = dev(hfull)[:, 1]                                # [b, cx, h, w] view with sample stride 3*cx*h*w
+    wt = rnd(4 * ch, cx, 3, 3, seed=61, scale=0.05)
+    bias = rnd(4 * ch, seed=62)
+    want = F.conv2d(hfull[:, 1].double(), wt.double(), bias.double(), padding=1)
+    wph, winv = ops.pack_conv3x3_h3(dev(wt))
+    nsteps = cx // 16
+    for k in (2, 4):
+        for cfg in range(lib.cm_conv3x3_split_num_configs()):
+            res = ops.conv3x3_parts(hx, 4 * ch, wph, winv, bias=dev(bias), config=ops.H3_BASE + cfg + (k << 8))
+            parts, kk = res
+            assert kk == k
+            assert rel_l2(parts[:k].double().sum(0), want) < 5e-6, (k, cfg)
+    # k = 8 > 4 k-steps and k = 3 (does not divide): refused by the launcher
+    stack = torch.empty(8, b, 4 * ch, h, w, device="cuda")
+    for bad in (3, 8):
+        rc = lib.cm_conv3x3_h3(hx.data_ptr(), hx.stride(0), cx, None, 0, 0, wph.data_ptr(), winv.data_ptr(), None, None, 0,
+                               stack.data_ptr(), stack.stride(1), None, 0, b, h, w, 4 * ch, (bad << 8) | (1 << 29),
+                               torch.cuda.current_stream().cuda_stream)
+        assert rc == -22, (bad, rc)
+    assert nsteps == 4
+    # autotuned call + exponent table
+    be = ops.SampleExponents(torch.zeros(b, device="cuda", dtype=torch.int32))
+    parts, k = ops.conv3x3_parts(hx, 4 * ch, wph, winv, be_out=be)
+    assert be.valid
+    want_be = ((hfull[:, 1].abs().amax((1, 2, 3)).view(torch.int32) >> 23) & 0xff)
+    assert torch.equal(be.t.cpu(), want_be.to(torch.int32))
+    # fused forward: gates = gx + sum(parts) -> activations, c, h
+    gx = dev(rnd(b, 4 * ch, h, w, seed=63)); cp = dev(rnd(b, ch, h, w, seed=64))
+    g_ref = gx + parts[:k].sum(0)
+    c_ref = torch.empty(b, ch, h, w, device="cuda"); h_ref = torch.empty_like(c_ref)
+    ops.lstm_gates_fwd(g_ref, cp, c_ref, h_ref)
+    g_fused = gx.clone(); c_f = torch.empty_like(c_ref); h_f = torch.empty_like(c_ref)
+    ops.lstm_gates_fwd(g_fused, cp, c_f, h_f, parts=(parts, k))
+    assert rel_l2(g_fused, g_ref) < 1e-6 and rel_l2(c_f, c_ref) < 1e-6 and rel_l2(h_f, h_ref) < 1e-6
+    # fused backward: dh = dh_a + sum(slices)
+    dparts = dev(rnd(4, b, ch, h, w, seed=65)); dha = dev(rnd(b, ch, h, w, seed=66)); dc0 = dev(rnd(b, ch, h, w, seed=67))
+    ga, gb = g_ref.clone(), g_ref.clone(); dca, dcb = dc0.clone(), dc0.clone()
+    ops.lstm_gates_bwd(ga, cp, c_ref, dha, dparts[:3].sum(0), dca, first=False)
+    ops.lstm_gates_bwd(gb, cp, c_ref, dha, (dparts, 3), dcb, first=False)
+    assert rel_l2(gb, ga) < 1e-6 and rel_l2(dcb, dca) < 1e-6
+
+
 # --------------------------------------------------------------------------------------------- head / loss / adam
 def test_head_and_mse(ops):
     n, c, oc, h, w = 3, 16, 2, 16, 24
