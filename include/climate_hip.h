@@ -132,6 +132,12 @@ int cm_wgrad3x3_unpack_batch(const void* descs_dev, int ndesc, int total_blocks,
  * mean_hw(y) per (n,c) = SEBlock's AdaptiveAvgPool2d(1) (src/unet.py:10).  x, y, dx are contiguous [n,c,hw].     */
 int cm_gn_silu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, float* pooled,
                    int n, int c, int hw, int groups, float eps, cm_stream stream);
+/* cm_gn_silu_fwd fed by a "partial slices" convolution (cm_conv3x3_h3 config bit 29): x arrives as nparts contiguous
+ * [n,c,hw] slices zs apart; the launch adds them in slice order, writes the sum to xsum [n,c,hw] (the conv output the
+ * backward reads) and proceeds as cm_gn_silu_fwd(xsum, ...). */
+int cm_gn_silu_fwd_parts(const float* parts, long long zs, int nparts, float* xsum, const float* gamma,
+                         const float* beta, float* y, float* stats, float* pooled, int n, int c, int hw, int groups,
+                         float eps, cm_stream stream);
 /* dA = gradient wrt y (sample stride st_dA); dgamma/dbeta are ACCUMULATED (atomics). */
 int cm_gn_silu_bwd(const float* x, const float* gamma, const float* beta, const float* stats, const float* dA,
                    long long st_dA, float* dx, float* dgamma, float* dbeta, int n, int c, int hw, int groups,

@@ -47,21 +47,48 @@ __device__ __forceinline__ float gn_silu_value(float v, float ga, float be) {
   return gn_silu_parts(v, ga, be, u, sg);
 }
 
-template <bool VEC, int LPC>   // LPC lanes cooperate on one channel (64: a wave, 16: four channels per wave)
+// PARTS: x arrives as nparts partial sums (slices zs apart: what a "partial slices" cm_conv3x3_h3 launch stores); the
+// statistics pass adds them in slice order, WRITES the sum to xsum (the conv output the backward needs) and the apply pass
+// re-reads it from there like the plain form re-reads x.
+template <bool VEC, int LPC, bool PARTS>   // LPC lanes cooperate on one channel (64: a wave, 16: four channels per wave)
 __global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_kernel(const float* __restrict__ x,
                                                                    const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta,
                                                                    float* __restrict__ y, float* __restrict__ stats,
                                                                    float* __restrict__ pooled, int C, int HW,
-                                                                   int G, float eps) {
+                                                                   int G, float eps, const float* __restrict__ parts,
+                                                                   long long zs, int nparts, float* xsum) {
   __shared__ float red[32];
   const int n = blockIdx.x / G, g = blockIdx.x % G;
   const int cpg = C / G;
   const long long base = ((long long)n * C + (long long)g * cpg) * HW;
   const int L = cpg * HW;
-  const float* xg = x + base;
+  const float* xg = PARTS ? xsum + base : x + base;
   float* yg = y + base;
   const int tid = threadIdx.x;
+  if constexpr (PARTS) {
+    // sum the slices into xsum first (one pass; the statistics below read it back from L2 like the plain form reads x)
+    const float* pg = parts + base;
+    float* sg = xsum + base;
+    if (VEC) {
+      for (int i = tid; i < L / 4; i += GN_THREADS) {
+        float4 v = reinterpret_cast<const float4*>(pg)[i];
+        for (int z = 1; z < nparts; ++z) {
+          const float4 u = reinterpret_cast<const float4*>(pg + z * zs)[i];
+          v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        reinterpret_cast<float4*>(sg)[i] = v;
+      }
+    } else {
+      for (int i = tid; i < L; i += GN_THREADS) {
+        float v = pg[i];
+        for (int z = 1; z < nparts; ++z) v += pg[z * zs + i];
+        sg[i] = v;
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
 
   // one statistics pass: sums of (x - pivot) and (x - pivot)^2.  The pivot is the mean of a 256-element sample spread
   // over the whole group, i.e. within ~sigma/16 of the group mean, so E[d^2] - E[d]^2 does not cancel (a single
@@ -515,7 +542,22 @@ int cm_gn_silu_fwd(const float* x, const float* gamma, const float* beta, float*
     CM_CHECK_LAUNCH();
     return 0;
   }
-#define GN_FWD(V, L) gn_silu_fwd_kernel<V, L><<<n * groups, GN_THREADS, 0, st>>>(x, gamma, beta, y, stats, pooled, c, hw, groups, eps)
+#define GN_FWD(V, L) gn_silu_fwd_kernel<V, L, false><<<n * groups, GN_THREADS, 0, st>>>(x, gamma, beta, y, stats, pooled, c, hw, groups, eps, nullptr, 0, 0, nullptr)
+  if (vec) { if (narrow) GN_FWD(true, 16); else GN_FWD(true, 64); }
+  else     { if (narrow) GN_FWD(false, 16); else GN_FWD(false, 64); }
+#undef GN_FWD
+  CM_CHECK_LAUNCH();
+  return 0;
+}
+
+int cm_gn_silu_fwd_parts(const float* parts, long long zs, int nparts, float* xsum, const float* gamma,
+                         const float* beta, float* y, float* stats, float* pooled, int n, int c, int hw, int groups,
+                         float eps, cm_stream stream) {
+  if (n <= 0 || c <= 0 || hw <= 0 || groups <= 0 || c % groups || nparts < 1 || !parts || !xsum) return -22;
+  const bool vec = (hw % 4) == 0 && (zs % 4) == 0;
+  const bool narrow = (vec ? hw / 4 : hw) <= 64 && (c / groups) >= 8;
+  hipStream_t st = (hipStream_t)stream;
+#define GN_FWD(V, L) gn_silu_fwd_kernel<V, L, true><<<n * groups, GN_THREADS, 0, st>>>(nullptr, gamma, beta, y, stats, pooled, c, hw, groups, eps, parts, zs, nparts, xsum)
   if (vec) { if (narrow) GN_FWD(true, 16); else GN_FWD(true, 64); }
   else     { if (narrow) GN_FWD(false, 16); else GN_FWD(false, 64); }
 #undef GN_FWD

@@ -60,6 +60,7 @@ USE_H3 = NUMERICS == "fp16x3"
 # data gradient of it run as "partial slices" launches (reduction shares stored, not added with atomics) whose slices the
 # pointwise gate kernels add while they read their other operands.  CM_LSTM_PARTS=0 restores the atomic form.
 PARTIAL_SLICES = os.environ.get("CM_LSTM_PARTS", "1") != "0"
+CONV_PARTS = os.environ.get("CM_CONV_PARTS", "1") != "0"      # the same form for the small forward convs of a ConvBlock
 
 
 class _Packs:
@@ -80,12 +81,12 @@ class _Packs:
         self.uses_fp32[key] = self.uses_fp32.get(key, False) or ops.LAST_CONV_CONFIG < ops.SPLIT_BASE
         return out
 
-    def conv_parts(self, key, x0, cout, parts=None, be_out=None):
+    def conv_parts(self, key, x0, cout, parts=None, be_out=None, x1=None):
         """The same conv as k stored partial sums (ops.conv3x3_parts) -- or None when this weight has no fp16x3 operand
         or the reduction is too short; the caller then uses ``conv``."""
         if not PARTIAL_SLICES or key not in self.pkh:
             return None
-        res = ops.conv3x3_parts(x0, cout, self.pkh[key], self.winv[key], parts=parts, be_out=be_out)
+        res = ops.conv3x3_parts(x0, cout, self.pkh[key], self.winv[key], parts=parts, be_out=be_out, x1=x1)
         if res is not None:
             self.uses_fp32.setdefault(key, False)
         return res
@@ -293,15 +294,34 @@ class _BeArena:
         return ops.SampleExponents(t)
 
 
+def _small_launch(x: Tensor, cin: int, cout: int) -> bool:
+    """A forward conv whose grid cannot fill the chip and whose reduction is a chain of >= 4 stages (the 16-frame decoder
+    launches and the H/8 level at the micro-batch shapes): it runs as stored partial slices over more workgroups
+    (stage_cost_probe: 4.4 us + 1.7 us per 16-channel stage for one workgroup per CU) and GroupNorm adds the slices."""
+    n, _, h, w = x.shape
+    return PARTIAL_SLICES and CONV_PARTS and cin >= 64 and cin % 16 == 0 and n * h * w * cout <= 1400000
+
+
 def _block_fwd(p: Params, pk, prefix: str, x0: Tensor, x1: Optional[Tensor], save: bool, pool: bool = False,
                bea: Optional[_BeArena] = None):
     co = p[prefix + "body.0.weight"].shape[0]
     # tables: [x of conv 1, x of conv 2 (a1), dy of conv 1, dy of conv 2]
     be = [bea.take(x0.shape[0]) for _ in range(4)] if (save and bea is not None) else [None] * 4
-    y1 = pk.conv(prefix + "body.0.weight/f", x0, co, x1=x1, be_out=be[0])
-    a1, st1, _ = ops.gn_silu_fwd(y1, p[prefix + "body.1.weight"], p[prefix + "body.1.bias"])
-    y2 = pk.conv(prefix + "body.3.weight/f", a1, co, be_out=be[1])
-    a2, st2, pooled = ops.gn_silu_fwd(y2, p[prefix + "body.4.weight"], p[prefix + "body.4.bias"], want_pooled=True)
+    # launches too small to fill the chip run as partial slices that the GroupNorm launch adds (see _small_launch)
+    ci = x0.shape[1] + (0 if x1 is None else x1.shape[1])
+    r1 = pk.conv_parts(prefix + "body.0.weight/f", x0, co, x1=x1, be_out=be[0]) if _small_launch(x0, ci, co) else None
+    if r1 is not None:
+        a1, st1, _, y1 = ops.gn_silu_fwd(None, p[prefix + "body.1.weight"], p[prefix + "body.1.bias"], parts=r1)
+    else:
+        y1 = pk.conv(prefix + "body.0.weight/f", x0, co, x1=x1, be_out=be[0])
+        a1, st1, _ = ops.gn_silu_fwd(y1, p[prefix + "body.1.weight"], p[prefix + "body.1.bias"])
+    r2 = pk.conv_parts(prefix + "body.3.weight/f", a1, co, be_out=be[1]) if _small_launch(a1, co, co) else None
+    if r2 is not None:
+        a2, st2, pooled, y2 = ops.gn_silu_fwd(None, p[prefix + "body.4.weight"], p[prefix + "body.4.bias"],
+                                              want_pooled=True, parts=r2)
+    else:
+        y2 = pk.conv(prefix + "body.3.weight/f", a1, co, be_out=be[1])
+        a2, st2, pooled = ops.gn_silu_fwd(y2, p[prefix + "body.4.weight"], p[prefix + "body.4.bias"], want_pooled=True)
     res = ops.se_spatial_gate_fwd(a2, pooled, p[prefix + "se.fc.0.weight"], p[prefix + "se.fc.2.weight"],
                                   p[prefix + "spat.conv.weight"], pool_out=pool)
     out, z, s, fmap, gate = res[:5]

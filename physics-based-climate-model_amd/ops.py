@@ -249,7 +249,7 @@ def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1, w
 PART_SLICES = (2, 4, 8)      # reduction splits the partial-slices form of a conv may use
 
 
-def conv3x3_parts(x0, cout, wph, winv, bias=None, parts=None, config=-1, be_out=None):
+def conv3x3_parts(x0, cout, wph, winv, bias=None, parts=None, config=-1, be_out=None, x1=None):
     """"Partial slices" form of the fp16x3 conv for launches that are too small to fill the chip (the ConvLSTM's
     recurrent projection and its data gradient): the reduction is split k ways over blockIdx.z and share z STORES its
     partial sums into slice z of ``parts`` [max(PART_SLICES), N, cout, H, W] -- no zero fill, no atomics (they were half
@@ -258,9 +258,10 @@ def conv3x3_parts(x0, cout, wph, winv, bias=None, parts=None, config=-1, be_out=
     posts the maxima of the channels it read).  Returns None when the reduction has
     fewer than two 16-channel k-steps (the caller uses conv3x3)."""
     n, c0, h, w = x0.shape
-    nsteps = (c0 + 15) // 16
+    c1 = 0 if x1 is None else x1.shape[1]
+    nsteps = (c0 + c1 + 15) // 16
     ks = [k for k in PART_SLICES if nsteps % k == 0 and k <= nsteps]
-    if not ks or wph is None:
+    if not ks or wph is None or (c1 and c0 % 16):
         return None
     if x0.stride(3) != 1 or x0.stride(2) != w or x0.stride(1) != h * w:
         raise RuntimeError("conv3x3_parts needs dense HxW planes with channel stride H*W")
@@ -270,12 +271,13 @@ def conv3x3_parts(x0, cout, wph, winv, bias=None, parts=None, config=-1, be_out=
         raise RuntimeError("conv3x3_parts: parts must be a contiguous [>= k, N, cout, H, W] stack")
 
     def call(cfg, dst, be=None):
-        return lib.cm_conv3x3_h3(_p(x0), x0.stride(0), c0, None, 0, 0, _p(wph), _p(winv), _p(bias), None, 0, _p(dst),
-                                 dst.stride(1), None if be is None else _p_any(be.t), 0 if be is None else be.stride,
+        return lib.cm_conv3x3_h3(_p(x0), x0.stride(0), c0, _p(x1), 0 if x1 is None else x1.stride(0), c1, _p(wph),
+                                 _p(winv), _p(bias), None, 0, _p(dst), dst.stride(1),
+                                 None if be is None else _p_any(be.t), 0 if be is None else be.stride,
                                  n, h, w, cout, (cfg - H3_BASE) | (1 << 29), _stream())
     if config < 0:
         cands = [H3_BASE + c + (k << 8) for c in range(lib.cm_conv3x3_split_num_configs()) for k in ks]
-        config = _pick(("conv3x3p", n, h, w, c0, cout), cands, lambda cfg: call(cfg, parts), H3_BASE + (ks[0] << 8))
+        config = _pick(("conv3x3p", n, h, w, c0, c1, cout), cands, lambda cfg: call(cfg, parts), H3_BASE + (ks[0] << 8))
     check(call(config, parts, be_out), "conv3x3_h3 (partial slices)")
     if be_out is not None:
         be_out.valid = True
@@ -412,7 +414,19 @@ def wgrad3x3_unpack(g, scale=1.0):
 
 
 # ----------------------------------------------------------------------------------------------------- GN + SiLU
-def gn_silu_fwd(x, gamma, beta, want_pooled=False):
+def gn_silu_fwd(x, gamma, beta, want_pooled=False, parts=None):
+    """parts = (stack [>= k, N, C, H, W], k) from conv3x3_parts instead of x: the launch adds the slices and returns the
+    summed conv output as a fourth value (x is ignored)."""
+    if parts is not None:
+        pt, k = parts
+        _, n, c, h, w = pt.shape
+        xs = torch.empty(n, c, h, w, device=pt.device, dtype=torch.float32)
+        y = torch.empty_like(xs)
+        stats = torch.empty(n * GN_GROUPS * 2, device=pt.device, dtype=torch.float32)
+        pooled = torch.empty(n, c, device=pt.device, dtype=torch.float32) if want_pooled else None
+        check(lib.cm_gn_silu_fwd_parts(_p(pt), pt.stride(0), k, _p(xs), _p(gamma), _p(beta), _p(y), _p(stats), _p(pooled),
+                                       n, c, h * w, GN_GROUPS, GN_EPS, _stream()), "gn_silu_fwd_parts")
+        return y, stats, pooled, xs
     n, c, h, w = x.shape
     y = torch.empty_like(_contig(x))
     stats = torch.empty(n * GN_GROUPS * 2, device=x.device, dtype=torch.float32)

@@ -512,6 +512,20 @@ def test_conv_partial_slices_and_lstm_gates_parts(ops):
     g_fused = gx.clone(); c_f = torch.empty_like(c_ref); h_f = torch.empty_like(c_ref)
     ops.lstm_gates_fwd(g_fused, cp, c_f, h_f, parts=(parts, k))
     assert rel_l2(g_fused, g_ref) < 1e-6 and rel_l2(c_f, c_ref) < 1e-6 and rel_l2(h_f, h_ref) < 1e-6
+    # GroupNorm + SiLU fed by slices == GroupNorm + SiLU of their sum (and the sum is handed back as the conv output)
+    for (nn, cc, hh, ww) in ((3, 64, 6, 9), (2, 16, 5, 7), (2, 128, 12, 18)):
+        st = dev(rnd(4, nn, cc, hh, ww, seed=70)); ga = dev(rnd(cc, seed=71)); bt = dev(rnd(cc, seed=72))
+        xs = st[:3].sum(0)
+        y0, s0, p0 = ops.gn_silu_fwd(xs, ga, bt, want_pooled=True)
+        y1, s1, p1, x1s = ops.gn_silu_fwd(None, ga, bt, want_pooled=True, parts=(st, 3))
+        assert rel_l2(x1s, xs) < 1e-6 and rel_l2(y1, y0) < 1e-6 and rel_l2(s1, s0) < 1e-6 and rel_l2(p1, p0) < 1e-6
+    # two-input (virtual concat) conv as slices
+    xa = dev(rnd(2, 32, 12, 18, seed=73)); xb = dev(rnd(2, 32, 12, 18, seed=74))
+    wt2 = rnd(24, 64, 3, 3, seed=75, scale=0.05)
+    wph2, winv2 = ops.pack_conv3x3_h3(dev(wt2))
+    pr, k2 = ops.conv3x3_parts(xa, 24, wph2, winv2, x1=xb)
+    want2 = F.conv2d(torch.cat([xa, xb], 1).double().cpu(), wt2.double(), padding=1)
+    assert rel_l2(pr[:k2].double().sum(0), want2) < 5e-6
     # fused backward: dh = dh_a + sum(slices)
     dparts = dev(rnd(4, b, ch, h, w, seed=65)); dha = dev(rnd(b, ch, h, w, seed=66)); dc0 = dev(rnd(b, ch, h, w, seed=67))
     ga, gb = g_ref.clone(), g_ref.clone(); dca, dcb = dc0.clone(), dc0.clone()

@@ -22,6 +22,6 @@ for name, n, c0, c1, co, h, w in layers(32, 16, 6):
         parts = r[0]
         g = lambda: ops.conv3x3_parts(x, co_, wph, winv, parts=parts)
         g(); t1 = timeit(g, 20)
-        key = ("conv3x3p", n, h, w, ci_, co_)
+        key = ("conv3x3p", n, h, w, ci_, 0, co_)
         print(f"{name:8s} {tag:5s} N{n:3d} {ci_:4d}->{co_:4d} {h}x{w}: tuned {t0:6.1f} us (cfg {ops.LAST_CONV_CONFIG - ops.H3_BASE:5d})  "
               f"parts {t1:6.1f} us (k {r[1]}, cfg {(ops._TUNED[key] - ops.H3_BASE) & 255})", flush=True)
