@@ -16,6 +16,11 @@ python bench.py --steps 30 --warmup 5 > $out/bench.json 2> $out/bench.err || { t
 python tools/show_bench.py $out/bench.json > $out/bench_table.txt; head -8 $out/bench_table.txt
 #   2b. secondary line: BASELINE configs[3] (cnn_transformer, training mode with dropout)
 python bench.py --model cnn_transformer --steps 30 --warmup 5 > $out/bench_cnn_transformer.json 2> $out/bench_cnn_transformer.err && python tools/show_bench.py $out/bench_cnn_transformer.json > $out/bench_cnn_transformer_table.txt && head -6 $out/bench_cnn_transformer_table.txt
+#   2c. one rank's share of BASELINE configs 3 and 5 (set CM_MEASURE_BIG=0 to skip: ~2.5 minutes)
+if [ "${CM_MEASURE_BIG:-1}" != "0" ]; then
+  python bench.py --base 64 --seq-len 12 --steps 10 --warmup 3 > $out/bench_config3_one_rank.json 2> $out/bench_config3.err
+  python bench.py --base 64 --height 192 --width 288 --batch 16 --steps 5 --warmup 2 > $out/bench_config5_one_rank.json 2> $out/bench_config5.err
+fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --profile-steps 0 > $out/stats.log 2>&1
 f=$(ls $out/stats/*/*kernel_stats.csv 2>/dev/null | tail -1); [ -n "$f" ] && cp $f $out/rocprofv3_kernel_stats.csv && python tools/stats_by_family.py $out/rocprofv3_kernel_stats.csv > $out/rocprofv3_kernel_stats_by_family.txt
 t=$(ls $out/stats/*/*kernel_trace.csv 2>/dev/null | tail -1); [ -n "$t" ] && python tools/trace_summary.py $t --one-step > $out/one_step_trace.txt
