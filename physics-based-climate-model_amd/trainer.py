@@ -332,9 +332,11 @@ class InferenceRunner:
     shape into a hipGraph and replayed; the returned prediction tensor is the graph's static output (copy it if it
     must survive the next call)."""
 
-    def __init__(self, model, use_graph: bool = True):
+    def __init__(self, model, use_graph: bool = True, micro_batches: Optional[int] = None):
         self.model = model
         self.use_graph = use_graph
+        self.micro_batches = micro_batches      # None: two halves on two streams for small workloads (see _fwd)
+        self._side = None
         self._graphs = {}
         self._plans = []
 
@@ -343,8 +345,27 @@ class InferenceRunner:
         plan = engine.get_plan(p, None, False)
         if not any(q is plan for q in self._plans):
             self._plans.append(plan)
-        pred, _ = self.model._engine_forward(p, plan.pack(), x, save=False)
-        return pred
+        pk = plan.pack()
+        B = x.shape[0]
+        # two halves of the batch on two streams (same reasoning and same choice as HotPathTrainer._auto_micro); models
+        # with per-call device state (the cnn_transformer in training mode) keep the one-batch schedule
+        two = (self.micro_batches == 2 or (self.micro_batches is None and type(self.model).__name__ == "AttUNetConvLSTM"
+                                           and x.dim() == 5 and B % 2 == 0 and B >= 4
+                                           and float(B) * x.shape[1] * x.shape[3] * x.shape[4]
+                                           * getattr(self.model, "base", 1 << 10) ** 2 < 1e10))
+        if not two:
+            pred, _ = self.model._engine_forward(p, pk, x, save=False)
+            return pred
+        h = B // 2
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=x.device)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            p1, _ = self.model._engine_forward(p, pk, x[h:], save=False)
+        p0, _ = self.model._engine_forward(p, pk, x[:h], save=False)
+        main.wait_stream(self._side)
+        return torch.cat([p0, p1], 0)
 
     @torch.no_grad()
     def __call__(self, x: torch.Tensor) -> torch.Tensor:

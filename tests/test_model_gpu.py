@@ -494,6 +494,25 @@ def test_micro_batch_overlap_equals_one_batch(amd, use_graph):
     assert auto._auto_micro(torch.empty(3, 6, 5, 48, 72, device="meta")) == 1         # odd batch
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_inference_runner_matches_module_forward(amd, use_graph):
+    """InferenceRunner (validation_step / test_step: forward only, main_final.py:563-574) == the module's forward, one
+    batch and two halves on two streams, eager and through the replayed graph (second call = replay)."""
+    from climate_amd.trainer import InferenceRunner
+    in_ch, out_ch, base, T, B, H, W = 5, 2, 16, 3, 6, 16, 24
+    m = _make(amd, in_ch, out_ch, base, T)
+    gen = torch.Generator("cpu").manual_seed(77)
+    x = torch.randn(B, T, in_ch, H, W, generator=gen).cuda()
+    x2 = torch.randn(B, T, in_ch, H, W, generator=gen).cuda()
+    with torch.no_grad():
+        want, want2 = m(x).clone(), m(x2).clone()
+    for parts in (1, 2, None):
+        inf = InferenceRunner(m, use_graph=use_graph, micro_batches=parts)
+        assert rel_l2(inf(x), want) < 2e-6, parts
+        assert rel_l2(inf(x2), want2) < 2e-6, parts          # (graphed: a replay with new input)
+        assert rel_l2(inf(x), want) < 2e-6, parts
+
+
 # ----------------------------------------------------------------------------------------------- determinism / overlap
 def test_run_twice_determinism(amd):
     """Split-K convolutions and all weight gradients accumulate with fp32 atomics, so two runs are not bit-identical;
