@@ -11,9 +11,15 @@ itself (children, before anything touches a GPU in the parent; the parent only f
 
 One "step" = zero grads -> forward -> MSE -> backward -> (RCCL all-reduce) -> Adam on one synthetic batch of
 [32, 6, 5, 48, 72] per GPU (weak scaling), fp32, inputs resident in HBM.  Rank 0 prints ONE JSON line.
-Extra objects: "roofline" (dominant kernel = the fp32-MFMA conv3x3 implicit GEMM, timed with HIP events on the launch
-stream in a second, eager pass over the same workload) and "cpu_baseline" (the CPU oracle's full training step on
-this box's host cores; N=1 only).
+`value` = global samples / wall time of the K timed steps (max over ranks); `ms_per_step_median` = median of the per-step
+periods measured with HIP events on the launch stream around every graph replay.
+Extra objects: "roofline" (dominant kernel family = the fp16x3 split-operand conv3x3 implicit GEMM on the f16 matrix cores,
+every launch timed ALONE with HIP events on the launch stream in a second, eager pass over the same workload),
+"roofline_cell" (north_star's ConvLSTM-cell figure: algorithmic bytes and flops of the cell / the measured time of its
+launches, both fractions, which one binds), "step_hbm_frac" / "step_mfma_frac" (SURVEY 8(d) whole-step fractions),
+"numerics" (what `dtype: f32` means here, with the error measured in this run) and "cpu_baseline" (the CPU oracle's full
+training step on this box's host cores; N=1 only).  N > 1 adds "multi_gpu" (ranks seen, per-rank step times, exposed
+exchange time) and pins every rank to the CPU cores of its GPU's NUMA node before the first GPU call.
 """
 import argparse
 import json
@@ -74,6 +80,77 @@ def train_flops_per_sample(b, T, H, W, cin=5, cout=2):
     dec = up(4 * b, 4 * b, 4 * b, HW[2]) + up(4 * b, 2 * b, 2 * b, HW[1]) + up(2 * b, b, b, HW[0])
     head = 2 * b * cout * HW[0]
     return 3 * (T * enc + T * lstm + dec + head)
+
+
+def train_bytes_per_sample(b, T, H, W, cin=5, cout=2):
+    """SURVEY.md 8(d) / Appendix C cost model: fused-minimum HBM bytes per sample, training = 3 x forward."""
+    HW = [H * W, H * W // 4, H * W // 16, H * W // 64]
+    ch = [b, 2 * b, 4 * b, 8 * b]
+    blk = lambda ci, co, hw: 4 * hw * (ci + 7 * co)
+    enc = blk(cin, b, HW[0]) + sum(blk(ch[i - 1], ch[i], HW[i]) for i in (1, 2, 3))
+    pool = 4 * 1.25 * sum(ch[i] * HW[i] for i in (0, 1, 2))
+    Cx, Ch, hw = 8 * b, 4 * b, HW[3]
+    lstm = 4 * hw * (Cx + 8 * Ch)
+    up = lambda ci, cs, co, hwo: blk(co + cs, co, hwo) + 4 * (ci * hwo // 4 + co * hwo)
+    dec = up(4 * b, 4 * b, 4 * b, HW[2]) + up(4 * b, 2 * b, 2 * b, HW[1]) + up(2 * b, b, b, HW[0])
+    skip = 4 * (T + 1) * sum(ch[i] * HW[i] for i in (0, 1, 2))
+    head = 4 * (b + cout) * HW[0]
+    return 3 * (T * (enc + pool) + T * lstm + skip + dec + head)
+
+
+def cell_cost(b, H, W):
+    """ConvLSTM cell alone: per sample per time step (training): bytes, flops; weights bytes per step."""
+    Cx, Ch, hw = 8 * b, 4 * b, H * W // 64
+    return 4 * hw * (Cx + 8 * Ch), 18 * hw * (Cx + Ch) * 4 * Ch, 4 * (9 * (Cx + Ch) * 4 * Ch + 4 * Ch)
+
+
+def pin_to_gpu_numa(local_rank):
+    """Pin this process to the CPU cores of the NUMA node GPU `local_rank` hangs off -- from sysfs only, before anything
+    touches a GPU.  Best effort: returns a description, or None when the topology cannot be read (nothing is changed)."""
+    try:
+        import glob
+        gpus = []
+        for node in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*"), key=lambda q: int(q.rsplit("/", 1)[1])):
+            props = dict(l.split() for l in open(node + "/properties").read().splitlines() if len(l.split()) == 2)
+            if int(props.get("simd_count", "0")) > 0:
+                gpus.append(int(props.get("drm_render_minor", "-1")))
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+        if vis:
+            gpus = [gpus[int(i)] for i in vis.split(",") if i.strip().isdigit() and int(i) < len(gpus)]
+        minor = gpus[local_rank]
+        numa = int(open(f"/sys/class/drm/renderD{minor}/device/numa_node").read())
+        if numa < 0:
+            return None
+        cores = set()
+        for part in open(f"/sys/devices/system/node/node{numa}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cores.update(range(int(lo), int(hi or lo) + 1))
+        cores &= set(os.sched_getaffinity(0))
+        if not cores:
+            return None
+        os.sched_setaffinity(0, cores)
+        return {"numa_node": numa, "cores": len(cores)}
+    except Exception:
+        return None
+
+
+def measure_conv_numerics(dev):
+    """What `dtype: f32` means on this line: fp32 storage and accumulation, conv products emulated with two fp16 pieces per
+    operand (3 MFMA products).  Returns the relative L2 error of one representative layer (128 -> 128 channels, 12x18,
+    8 samples) against float64, measured now, beside torch-CPU fp32's error on the same operands."""
+    import torch.nn.functional as F
+    from climate_amd import ops
+    g = torch.Generator("cpu").manual_seed(7)
+    x = torch.randn(8, 128, 12, 18, generator=g)
+    w = torch.randn(128, 128, 3, 3, generator=g) * (1.0 / (128 * 9) ** 0.5)
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    wph, winv = ops.pack_conv3x3_h3(w.to(dev))
+    y = ops.conv3x3(x.to(dev), None, 128, wph=wph, winv=winv)
+    err = ((y.double().cpu() - ref).norm() / ref.norm()).item()
+    err32 = ((F.conv2d(x, w, padding=1).double() - ref).norm() / ref.norm()).item()
+    return {"storage": "f32", "accumulate": "f32", "conv_products": "fp16x3 (two fp16 pieces per operand, 3 MFMA products, "
+            "exact power-of-two scaling)", "rel_err_vs_fp64": float(f"{err:.3g}"), "torch_cpu_f32_rel_err_vs_fp64":
+            float(f"{err32:.3g}"), "layer": "conv3x3 128->128, 12x18, 8 samples", "parity_bound": 1e-4}
 
 
 def _which_config(base, T, H, W):
@@ -274,6 +351,7 @@ def main():
     from climate_amd.trainer import HotPathTrainer
     import torch.distributed as dist
 
+    affinity = pin_to_gpu_numa(int(os.environ.get("LOCAL_RANK", "0"))) if args.gpus > 1 else None
     rank, local, world = ddp.init_from_env(backend=args.backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
@@ -308,16 +386,42 @@ def main():
     for _ in range(args.warmup):
         tr.step(x, y)
     barrier()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        marks[i].record()                      # (on the launch stream: the period between two marks is one step)
         loss = tr.step(x, y)
+    marks[args.steps].record()
     barrier()
     dt = time.perf_counter() - t0
+    dt_local = dt
+    periods = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    ms_median = periods[len(periods) // 2]
+    multi = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                                      # ranks that really took part in a collective
+        lo = torch.tensor([dt_local], device=dev, dtype=torch.float64)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        multi = {"ranks_seen": int(ones.item()), "world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                 "ms_per_step_rank_min": round(lo.item() / args.steps * 1e3, 4),
+                 "ms_per_step_rank_max": round(dt / args.steps * 1e3, 4), "cpu_affinity": affinity}
     final_loss = loss.item()
+    if world > 1 and tr.use_graph:
+        # exposed exchange time: the same graphs replayed WITHOUT the two all-reduces (gradients stay local: the parameters
+        # of the ranks drift apart from here on -- nothing after this point uses them for a result)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            tr.step(x, y, exchange=False)
+        barrier()
+        dn = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        dist.all_reduce(dn, op=dist.ReduceOp.MAX)
+        multi["ms_per_step_without_exchange"] = round(dn.item() / args.steps * 1e3, 4)
+        multi["exchange_exposed_ms"] = round((dt - dn.item()) / args.steps * 1e3, 4)
 
     # ---- forward-only throughput and the PCIe leg of a host-resident batch (never part of `value`) -----
     fwd_sps, h2d = None, None
@@ -400,6 +504,38 @@ def main():
                                           "batch); in the timed region two such launch streams run side by side and the "
                                           "step takes 1/overlap_factor of their summed durations"}
 
+    cell, numerics = None, None
+    if rank == 0 and args.profile_steps > 0:
+        reg = kt.by_region()
+        cb, cf, cw = cell_cost(base, H, W)
+        out_cell = {}
+        for key, scale_f, passes in (("lstm_cell_fwd", 1.0, "forward: x-projection (all T, one launch) + T-1 recurrent "
+                                      "projections + T gate / state updates"),
+                                     ("lstm_cell_bwd", 2.0, "backward: T gate backward launches + T-1 recurrent data "
+                                      "gradients + x data gradient + both weight gradients + bias gradient")):
+            if key not in reg:
+                continue
+            ms = reg[key]["ms"] / args.profile_steps
+            # one direction moves the cell's training bytes once (SURVEY 8d counts 276 480 B/sample/step at config 2 for
+            # x, h, c in, h, c and the four gate maps out) plus the gate weights once per step per micro-batch
+            nbytes = B * T * cb + tr._parts * T * cw
+            flops = scale_f * B * T * cf
+            t_hbm, t_mfma = nbytes / (PEAK_HBM_GBPS * 1e9), 3 * flops / (PEAK_BF16_MFMA_TFLOPS * 1e12)
+            out_cell[key] = {"what": passes, "launches": reg[key]["calls"] / args.profile_steps, "ms": round(ms, 4),
+                             "algorithmic_bytes": int(nbytes), "algorithmic_flops": int(flops),
+                             "hbm_gbps": round(nbytes / (ms * 1e-3) / 1e9, 1),
+                             "hbm_frac": round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                             "mfma_tflops_executed": round(3 * flops / (ms * 1e-3) / 1e12, 1),
+                             "mfma_frac": round(3 * flops / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                             "bound": "mfma" if t_mfma > t_hbm else "hbm",
+                             "frac_of_binding_roofline": round(max(t_hbm, t_mfma) / (ms * 1e-3), 4)}
+        gates = [kernels[n] for n in ("cm_lstm_gates_fwd", "cm_lstm_gates_fwd_parts", "cm_lstm_step_fwd") if n in kernels]
+        cell = {"note": "north_star's '>= 40 % HBM roofline on the ConvLSTM cell' (SURVEY D5): the cell's convolution is a "
+                        "dense contraction (arithmetic intensity 384 flop/B at config 2), so the matrix cores bind, not HBM; "
+                        "both fractions are given per direction, timed as isolated launches at the micro-batch shape",
+                "bytes_per_sample_step": cb, "flops_per_sample_step": cf, "weight_bytes_per_step": cw, **out_cell}
+        numerics = measure_conv_numerics(dev)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # bounded sample: the default workload runs whole (5 steps, ~1.5 s on 16 cores); larger ones are cut to a
@@ -421,10 +557,15 @@ def main():
                                    f"per-GPU batch {B} ({_which_config(base, T, H, W)}), fwd+MSE+bwd+all-reduce+Adam",
                        "global_batch": gb, "seq_len": T, "parallelism": f"dp{world}",
                        "hip_graph": not args.no_graph, "micro_batches": tr._parts},
+            "ms_per_step_median": round(ms_median, 4),
             "step_mfma_frac": round(value / world * fl / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+            "step_hbm_frac": round((value / world * train_bytes_per_sample(base, T, H, W)
+                                    + (28 + (4 if world > 1 else 0)) * tr.nt / (dt / args.steps))
+                                   / (PEAK_HBM_GBPS * 1e9), 4),
+            "numerics": numerics, "multi_gpu": multi,
             "final_loss": final_loss,
             "fwd_samples_per_s": None if fwd_sps is None else round(fwd_sps, 1), "h2d": h2d,
-            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+            "roofline": roof, "roofline_cell": cell, "cpu_baseline": cpu, "kernels": kernels,
         }
         print(json.dumps(out))
         if os.environ.get("CM_TUNE_CACHE"):       # lets a profiled re-run skip the autotuner's trial launches

@@ -194,6 +194,55 @@ int cm_se_excite_bwd(const float* ds, const float* s, const float* z, const floa
                      const float* w2, float* dsig, float* dz, float* dpool, float* dw1, float* dw2, int n, int c,
                      int cr, cm_stream stream);
 
+/* ---- Sample-resident ConvBlock tail (csrc/block_tail.hip) --------------------------------------------------- *
+ * Everything of ConvBlock.forward after its second convolution -- GroupNorm(8) -> SiLU (src/unet.py:39), SEBlock
+ * (src/unet.py:6-17, called at :46), SpatialGate (src/unet.py:19-29, called at :47) and the encoder's MaxPool2d(2) of
+ * the result (src/unet_convlstm_attention.py:21,25) -- as ONE launch: a workgroup keeps one sample's conv output
+ * y2 [c,h,w] in registers, so y2 is read once and `out` written once.  Replaces the chain cm_gn_silu_fwd ->
+ * cm_se_spatial_stats -> cm_spatial_apply with the same outputs (stats, pooled, z, s, map, gate, out, mp) EXCEPT the
+ * activation a2 = SiLU(GroupNorm(y2)), which is not stored (cm_gn_silu_apply reproduces it bit for bit).
+ * Input: y2, or (y2 = NULL) `parts` = nparts partial slices of it zs floats apart (cm_conv3x3_h3 config bit 29), whose
+ * sum the launch also writes to ysum.  mp nullable ([n,c,h/2,w/2]).
+ * cm_block_tail_supported: 1 when a sample fits the register-resident layout (c % 8 == 0, h*w even, c*h*w <= 65536,
+ * <= 1024 pixel units: the H/2..H/8 levels at base 32, H/4..H/8 at base 64); otherwise callers keep the chain above. */
+int cm_block_tail_supported(int c, int cr, int h, int w);
+int cm_block_tail_fwd(const float* y2, const float* parts, long long zs, int nparts, float* ysum, const float* gamma,
+                      const float* beta, const float* w1, const float* w2, const float* w7, float* stats,
+                      float* pooled, float* z, float* s, float* fmap, float* gate, float* out, float* mp, int n, int c,
+                      int cr, int h, int w, float eps, cm_stream stream);
+/* The whole-sample reductions of that tail's backward in one launch (replaces cm_gate_bwd_reduce -> cm_conv7_bwd ->
+ * cm_se_bwd_reduce -> cm_se_excite_bwd; autograd of src/unet.py:16-17,26-29): from d(out), y2 and the forward's stats /
+ * s / z / gate / map it produces exactly what cm_gn_silu_bwd_gated consumes -- dmap [n,2,hw], umax / cnt [n,hw] (the
+ * backward's own channel maximum and tie count, cnt >= 1), dpool [n,c], dsig [n,c], dz [n,cr] -- and ACCUMULATES dw7 [98]. */
+int cm_block_tail_bwd(const float* y2, const float* stats, const float* gamma, const float* beta, const float* s,
+                      const float* z, const float* gate, const float* fmap, const float* w1, const float* w2,
+                      const float* w7, const float* dout, float* dmap, float* umax, float* cnt, float* dpool,
+                      float* dsig, float* dz, float* dw7, int n, int c, int cr, int h, int w, cm_stream stream);
+
+/* ---- SimpleCNN: BatchNorm2d (+ residual, + ReLU), Dropout2d, 1x1 skip convolutions (csrc/batchnorm.hip) ------ *
+ * ResidualBlock / SimpleCNN, src/models.py:44-123.  x, y, resid, dy, dx, dres are contiguous [n,c,hw].
+ * cm_bn_fwd: y = relu?(BatchNorm2d(x) + resid) (resid nullable: `out += self.skip(identity)`, src/models.py:72; relu:
+ * src/models.py:66,73,93,115).  training != 0: batch statistics (mean, biased variance over n*hw per channel), and
+ * running_mean / running_var (nullable) move by `momentum` towards the batch mean / UNBIASED variance (nn.BatchNorm2d
+ * defaults: momentum 0.1, eps 1e-5); training == 0: the running buffers normalise.  save [c][2] = {mean, rstd} used.
+ * cm_bn_bwd: g = dy * [y > 0] (relu != 0, y = the forward's output); dgamma += sum g*xhat, dbeta += sum g (one owner per
+ * channel, plain +=); dx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)) (training) or gamma*rstd*g (eval);
+ * dres (nullable) = g, the gradient of the residual input. */
+int cm_bn_fwd(const float* x, const float* gamma, const float* beta, const float* resid, float* y, float* save,
+              float* running_mean, float* running_var, float momentum, float eps, int relu, int training, int n, int c,
+              int hw, cm_stream stream);
+int cm_bn_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* save, float* dx,
+              float* dres, float* dgamma, float* dbeta, int relu, int training, int n, int c, int hw,
+              cm_stream stream);
+/* out[p][:] = x[p][:] * mult[p] for `planes` planes of hw floats: nn.Dropout2d (src/models.py:109,119) with the
+ * per-(sample, channel) multipliers 0 or 1/(1-p) in `mult`, forward and backward alike. */
+int cm_scale_planes(const float* x, const float* mult, float* out, long long planes, int hw, cm_stream stream);
+/* The 1x1 skip convolution of a ResidualBlock (src/models.py:57-59) runs on the 3x3 kernels: w3 [cout,cin,3,3] = w1
+ * [cout,cin,1,1] at the centre tap, zero elsewhere; its weight gradient is the centre tap of the 3x3 staging tensor
+ * G [cout][9][ctot] (cm_wgrad3x3*), ADDED to dw1 [cout,ctot]. */
+int cm_embed_center_tap(const float* w1, float* w3, int cout, int cin, cm_stream stream);
+int cm_extract_center_tap(const float* g, float* dw1, int cout, int ctot, cm_stream stream);
+
 /* ---- MaxPool2d(2), time-mean skips, per-channel sums ------------------------------------------------------- *
  * nn.MaxPool2d(2): src/unet_convlstm_attention.py:21,25.  stack(...).mean(0): src/unet_convlstm_attention.py:91-93. */
 int cm_maxpool2_fwd(const float* x, float* y, long long planes, int h, int w, cm_stream stream);

@@ -34,6 +34,7 @@ Tensor = torch.Tensor
 Params = Dict[str, Tensor]
 
 __all__ = [
+    "simple_cnn_forward",
     "se_block", "spatial_gate", "conv_block", "down_pool_enc", "up_block",
     "convlstm_cell", "convlstm", "model_forward", "training_loss",
     "adam_reference_step", "param_shapes", "closed_form_params", "GN_GROUPS", "GN_EPS",
@@ -432,3 +433,38 @@ def cnn_transformer_forward(p: Params, x: Tensor, n_heads: int, masks=None, deci
     y = _relu(F.conv_transpose2d(y, p["decoder.0.weight"], p["decoder.0.bias"], stride=2), dec, "decoder.0")
     y = _relu(F.conv_transpose2d(y, p["decoder.2.weight"], p["decoder.2.bias"], stride=2), dec, "decoder.2")
     return F.conv2d(y, p["decoder.4.weight"], p["decoder.4.bias"])
+
+
+# ----------------------------------------------------------------------------- SimpleCNN (BASELINE config 1)
+def simple_cnn_forward(p: Params, buffers: "Dict[str, Tensor]", x: Tensor, training: bool = False, drop_mask=None,
+                       decisions: "Optional[Decisions]" = None) -> Tensor:
+    """SimpleCNN.forward (src/models.py:117-123) over ResidualBlock.forward (src/models.py:61-75), functional.
+
+    ``p``: the reference's parameters by state_dict key; ``buffers``: its BatchNorm running_mean / running_var by
+    state_dict key.  training: nn.BatchNorm2d normalises with batch statistics and (as the module does) UPDATES the
+    running buffers in ``buffers`` in place (momentum 0.1, unbiased variance); eval: the running buffers normalise.
+    ``drop_mask`` [B, C]: the per-(sample, channel) multipliers (0 or 1/(1-p)) of nn.Dropout2d (src/models.py:109,119) --
+    None: no dropout (eval mode / p = 0).  ``decisions.relu`` (sites "initial", ("res", i, 1), ("res", i, 2), "final")
+    imposes another evaluation's ReLU decisions on the backward (see _relu)."""
+    dec = decisions
+
+    def bn(t, q):
+        return F.batch_norm(t, buffers[q + ".running_mean"], buffers[q + ".running_var"], p[q + ".weight"], p[q + ".bias"],
+                            training, 0.1, 1e-5)
+
+    y = _relu(bn(F.conv2d(x, p["initial.0.weight"], p["initial.0.bias"], padding=1), "initial.1"), dec, "initial")
+    i = 0
+    while f"res_blocks.{i}.conv1.weight" in p:
+        q = f"res_blocks.{i}."
+        out = _relu(bn(F.conv2d(y, p[q + "conv1.weight"], p[q + "conv1.bias"], padding=1), q + "bn1"), dec, ("res", i, 1))
+        out = bn(F.conv2d(out, p[q + "conv2.weight"], p[q + "conv2.bias"], padding=1), q + "bn2")
+        if q + "skip.0.weight" in p:
+            ident = bn(F.conv2d(y, p[q + "skip.0.weight"], p[q + "skip.0.bias"]), q + "skip.1")
+        else:
+            ident = y
+        y = _relu(out + ident, dec, ("res", i, 2))
+        i += 1
+    if drop_mask is not None:
+        y = y * drop_mask[:, :, None, None]
+    y = _relu(bn(F.conv2d(y, p["final.0.weight"], p["final.0.bias"], padding=1), "final.1"), dec, "final")
+    return F.conv2d(y, p["final.3.weight"], p["final.3.bias"])

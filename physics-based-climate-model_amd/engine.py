@@ -17,15 +17,23 @@ from typing import Dict, Optional
 
 import torch
 
-from . import ops
+from . import ops, profiler
 
 Tensor = torch.Tensor
 Params = Dict[str, Tensor]
 
 
 class _BlockCtx:
-    """Tensors one ConvBlock keeps for its backward."""
-    __slots__ = ("x0", "x1", "y1", "a1", "st1", "y2", "a2", "st2", "pooled", "z", "s", "fmap", "gate", "out", "be")
+    """Tensors one ConvBlock keeps for its backward.  ``a2`` (the activation entering the SE block) is None when the
+    sample-resident tail ran: it is never stored there and ``activation2()`` recomputes it bit-exactly."""
+    __slots__ = ("x0", "x1", "y1", "a1", "st1", "y2", "a2", "st2", "pooled", "z", "s", "fmap", "gate", "out", "be",
+                 "gn2")
+
+    def activation2(self):
+        """SiLU(GroupNorm(y2)), the stored tensor or its recomputation from the stored statistics (tests, probes)."""
+        if self.a2 is not None:
+            return self.a2
+        return ops.gn_silu_apply(self.y2, self.gn2[0], self.gn2[1], self.st2)
 
 
 def _conv_jobs(p: Params, need_input_grad: bool):
@@ -316,23 +324,31 @@ def _block_fwd(p: Params, pk, prefix: str, x0: Tensor, x1: Optional[Tensor], sav
         y1 = pk.conv(prefix + "body.0.weight/f", x0, co, x1=x1, be_out=be[0])
         a1, st1, _ = ops.gn_silu_fwd(y1, p[prefix + "body.1.weight"], p[prefix + "body.1.bias"])
     r2 = pk.conv_parts(prefix + "body.3.weight/f", a1, co, be_out=be[1]) if _small_launch(a1, co, co) else None
-    if r2 is not None:
-        a2, st2, pooled, y2 = ops.gn_silu_fwd(None, p[prefix + "body.4.weight"], p[prefix + "body.4.bias"],
-                                              want_pooled=True, parts=r2)
+    g2, b2 = p[prefix + "body.4.weight"], p[prefix + "body.4.bias"]
+    w1, w2, w7 = p[prefix + "se.fc.0.weight"], p[prefix + "se.fc.2.weight"], p[prefix + "spat.conv.weight"]
+    if ops.block_tail_supported(co, w1.shape[0], a1.shape[2], a1.shape[3]):
+        # the whole tail in one launch, one workgroup per sample (csrc/block_tail.hip); a2 is not materialised
+        y2 = None if r2 is not None else pk.conv(prefix + "body.3.weight/f", a1, co, be_out=be[1])
+        y2, st2, pooled, z, s, fmap, gate, out, mp = ops.block_tail_fwd(y2, g2, b2, w1, w2, w7, pool_out=pool, parts=r2)
+        a2 = None
     else:
-        y2 = pk.conv(prefix + "body.3.weight/f", a1, co, be_out=be[1])
-        a2, st2, pooled = ops.gn_silu_fwd(y2, p[prefix + "body.4.weight"], p[prefix + "body.4.bias"], want_pooled=True)
-    res = ops.se_spatial_gate_fwd(a2, pooled, p[prefix + "se.fc.0.weight"], p[prefix + "se.fc.2.weight"],
-                                  p[prefix + "spat.conv.weight"], pool_out=pool)
-    out, z, s, fmap, gate = res[:5]
+        if r2 is not None:
+            a2, st2, pooled, y2 = ops.gn_silu_fwd(None, g2, b2, want_pooled=True, parts=r2)
+        else:
+            y2 = pk.conv(prefix + "body.3.weight/f", a1, co, be_out=be[1])
+            a2, st2, pooled = ops.gn_silu_fwd(y2, g2, b2, want_pooled=True)
+        res = ops.se_spatial_gate_fwd(a2, pooled, w1, w2, w7, pool_out=pool)
+        out, z, s, fmap, gate = res[:5]
+        mp = res[5] if pool else None
     ctx = None
     if save:
         ctx = _BlockCtx()
         ctx.x0, ctx.x1, ctx.y1, ctx.a1, ctx.st1, ctx.y2, ctx.a2, ctx.st2 = x0, x1, y1, a1, st1, y2, a2, st2
         ctx.pooled, ctx.z, ctx.s, ctx.fmap, ctx.gate, ctx.out = pooled, z, s, fmap, gate, out
         ctx.be = be
+        ctx.gn2 = (g2, b2)
     if pool:
-        return out, ctx, res[5]
+        return out, ctx, mp
     return out, ctx
 
 
@@ -341,9 +357,15 @@ def _block_bwd(p: Params, pk, g: Params, gw: Params, ss: "_SideStream", prefix: 
     """Returns d(input) as one tensor [N, C0+C1, H, W] (or None); parameter gradients are accumulated into ``g``."""
     co = ctx.y1.shape[1]
     w1, w2, w7 = p[prefix + "se.fc.0.weight"], p[prefix + "se.fc.2.weight"], p[prefix + "spat.conv.weight"]
-    dmap, (umax, cnt), dpool, (dsig, dz) = ops.gates_bwd(dout, ctx.a2, ctx.s, ctx.z, ctx.pooled, ctx.gate, ctx.fmap, w1, w2, w7,
-                                                 g[prefix + "se.fc.0.weight"], g[prefix + "se.fc.2.weight"],
-                                                 g[prefix + "spat.conv.weight"], defer_se_wgrad=True)
+    if ctx.a2 is None:      # the sample-resident tail ran in the forward: its backward reductions are one launch too
+        dmap, (umax, cnt), dpool, (dsig, dz) = ops.block_tail_bwd(dout, ctx.y2, ctx.st2, p[prefix + "body.4.weight"],
+                                                                  p[prefix + "body.4.bias"], ctx.s, ctx.z, ctx.gate,
+                                                                  ctx.fmap, w1, w2, w7, g[prefix + "spat.conv.weight"])
+    else:
+        dmap, (umax, cnt), dpool, (dsig, dz) = ops.gates_bwd(dout, ctx.a2, ctx.s, ctx.z, ctx.pooled, ctx.gate, ctx.fmap,
+                                                             w1, w2, w7, g[prefix + "se.fc.0.weight"],
+                                                             g[prefix + "se.fc.2.weight"],
+                                                             g[prefix + "spat.conv.weight"], defer_se_wgrad=True)
     # (the SE weight gradients ride along with the GroupNorm backward launch)
     dy2 = ops.gn_silu_bwd_gated(ctx.y2, p[prefix + "body.4.weight"], p[prefix + "body.4.bias"], ctx.st2, ctx.a2, dout,
                                 ctx.gate, dmap, umax, cnt, ctx.s, dpool, g[prefix + "body.4.weight"],
@@ -387,19 +409,30 @@ class _SideStream:
     """Second HIP stream for the weight-gradient GEMMs.  They depend only on (layer input, upstream gradient) and
     feed nothing but the final unpack, so they run beside the main chain (data gradients + the HBM-bound
     normalisation / gate kernels) and fill the matrix pipes while those stream memory.  Works eagerly and under
-    hipGraph capture (fork/join through events).  Tensors handed to the side stream are kept alive until the join."""
+    hipGraph capture (fork/join through events).  Tensors handed to the side stream are kept alive until the join.
 
-    _streams: Dict[int, "torch.cuda.Stream"] = {}
+    One side stream per (device, PARENT stream): the two micro-batch halves of the trainer run on two streams, and each
+    must fork into a child of its own.  (Round 2 kept one side stream per device: both halves then forked into -- and
+    joined from -- the SAME child, which cross-links the two capture branches: the child waits on an event of half A,
+    then on one of half B, and both halves join on it.  That is the topology behind the recorded hipStreamEndCapture
+    crash, profiles/r03/capture_fork_probe.txt.)"""
+
+    _streams: Dict[tuple, "torch.cuda.Stream"] = {}
+
+    @staticmethod
+    def child_of(device, parent: "torch.cuda.Stream") -> "torch.cuda.Stream":
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        key = (idx, parent.cuda_stream)
+        if key not in _SideStream._streams:
+            _SideStream._streams[key] = torch.cuda.Stream(device=device)
+        return _SideStream._streams[key]
 
     def __init__(self, device, enabled: bool):
         self.enabled = enabled
         self.keep = []
         if enabled:
-            idx = device.index if device.index is not None else torch.cuda.current_device()
-            if idx not in _SideStream._streams:
-                _SideStream._streams[idx] = torch.cuda.Stream(device=device)
-            self.side = _SideStream._streams[idx]
             self.main = torch.cuda.current_stream(device)
+            self.side = _SideStream.child_of(device, self.main)
 
     def run(self, fn, *tensors):
         if not self.enabled:
@@ -416,22 +449,25 @@ class _SideStream:
         self.keep.clear()
 
 
-# Both side-stream overlaps are OFF by default (0-4 % either way on config 2, box dependent; with the fp32 weight-gradient
-# kernel 5 % slower).  Round 1 saw non-finite values in EAGER mode with CM_OVERLAP_WGRAD=1: the gate backward compared
-# a2*s with the channel maximum the forward had STORED, once received a stale SE scale `s`, found no channel equal to
-# the stored maximum, and divided by a tie count of 0.  Round 2: both load forms compile to
-# vector-memory loads through the same L1 (no scalar cache involved); tools/overlap_probe.py re-runs the suspected
-# uniform 16-byte form under the overlapped eager schedule and compares every launch's maxima with a serial
-# recomputation -- 0 mismatches in 56 launches, the failure does not reproduce on the current stack; and the gate
-# backward no longer depends on bitwise agreement with another launch: it derives maximum AND tie count from the values
-# it reads itself (count >= 1 by construction).  tests/test_model_gpu.py::test_side_stream_overlap_eager_three_steps runs three
-# eager steps of the overlapped schedule against the serial one.
-OVERLAP_WGRAD = os.environ.get("CM_OVERLAP_WGRAD", "0") != "0"
+# Both side-stream overlaps are OFF and cannot be switched on from the environment (they are module attributes that only
+# a test or a probe sets, e.g. tests/test_model_gpu.py::test_side_stream_overlap_eager_three_steps): they measure 0-4 %
+# either way on config 2, and round 1 saw non-finite values in EAGER mode with the weight-gradient overlap on -- the
+# gate backward compared a2*s with the channel maximum the forward had STORED, once received a stale SE scale `s`,
+# found no channel equal to the stored maximum, and divided by a tie count of 0.  The stale read was never reproduced
+# (tools/overlap_probe.py: 0 mismatches in 56 launches) and the gate backward no longer depends on bitwise agreement with
+# another launch (it derives maximum AND tie count from the values it reads itself, count >= 1 by construction), but
+# until the read is explained the schedule stays out of reach of a production run.
+OVERLAP_WGRAD = False
+# Under graph capture a stream that ENTERS the capture from a non-origin stream (a fork inside a forked stream: the child of
+# the second micro-batch's stream) crashes hipStreamEndCapture on this runtime; children that entered as first-level forks of
+# the origin and only pick up dependency edges from other captured streams later are fine (tools/capture_fork_probe.py,
+# profiles/r03/capture_fork_probe.txt).  The trainer pre-forks the side streams from the origin when this is set.
+PREFORK_OK = True
 
 # The ConvLSTM recurrence is a serial chain of small launches (N = B samples at 6x9: <= 256 workgroups each) that leaves
 # most of the chip idle.  Work that does not depend on it can run beside it on the side stream: the three time-mean
-# skips in the forward, the decoder's (deferred) weight gradients in the backward (~0.5 % of the step).
-OVERLAP_LSTM = os.environ.get("CM_OVERLAP_LSTM", "0") != "0"
+# skips in the forward, the decoder's (deferred) weight gradients in the backward (~0.5 % of the step).  Off, see above.
+OVERLAP_LSTM = False
 
 
 class _Deferred:
@@ -603,7 +639,8 @@ def forward(p: Params, pk, x_seq: Tensor, save: bool = True, head: bool = True):
     skips = []
     side = _SideStream(x.device, OVERLAP_LSTM)
     side.run(lambda: skips.extend(ops.time_mean(sk, B, T) for sk in (s1, s2, s3)), s1, s2, s3)
-    bott, lctx = convlstm_fwd(p, pk, s4, B, T, save, bea=bea)
+    with profiler.region("lstm_cell_fwd"):
+        bott, lctx = convlstm_fwd(p, pk, s4, B, T, save, bea=bea)
     side.join()
     k1, k2, k3 = skips
 
@@ -646,8 +683,9 @@ def backward_decoder_lstm(p: Params, pk, g: Params, sv: Saved, dpred: Optional[T
     dd3, dcat2 = up_bwd(p, pk, g, gw, dss, "up2.", u2, dd2)
     dbott, dcat3 = up_bwd(p, pk, g, gw, dss, "up3.", u3, dd3)
     side = _SideStream(dev, dec.enabled)
-    ds4 = convlstm_bwd(p, pk, g, gw, ss, sv.lstm, dbott,
-                       before_chain=lambda: side.run(dec.flush, *list(dec.keep)))   # (kept alive until the join)
+    with profiler.region("lstm_cell_bwd"):
+        ds4 = convlstm_bwd(p, pk, g, gw, ss, sv.lstm, dbott,
+                           before_chain=lambda: side.run(dec.flush, *list(dec.keep)))   # (kept alive until the join)
     st = _BwdState()
     st.plan, st.ss, st.side, st.ds4, st.dcat, st.split = plan, ss, side, ds4, (dcat1, dcat2, dcat3), bucketed
     if bucketed:

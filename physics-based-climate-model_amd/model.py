@@ -11,8 +11,8 @@ both ways, and the same default initialisation under ``torch.manual_seed``): the
 tensors to the engine (HIP kernels) through one ``autograd.Function`` so that the harness's ``loss.backward()``
 works unchanged.  There is no CPU path for these classes: a CPU input raises ``RuntimeError``.
 
-``cnn_transformer`` (BASELINE.json configs[3]) lives in ``cnn_transformer.py`` (HIP path as well); ``SimpleCNN``
-(configs[0], "CPU plumbing, no GPU") is the stock-torch module of ``host_models.py``.
+``cnn_transformer`` (BASELINE.json configs[3]) lives in ``cnn_transformer.py``, ``SimpleCNN`` (configs[0]) in
+``simple_cnn.py`` -- both on the HIP path as well.
 """
 from typing import Dict, List
 
@@ -278,7 +278,8 @@ def get_model(cfg):
       * ``unet``                    -> UNet on the HIP engine (same kernels, single frame);
       * ``cnn_transformer``         -> CNNTransformer on the HIP path (cnn_transformer.py: fp16x3 GEMMs, attention,
                                        LayerNorm kernels; dropout-free function, see that module);
-      * ``SimpleCNN``               -> the stock-torch SimpleCNN (BASELINE configs[0]: "CPU PyTorch, plumbing").
+      * ``SimpleCNN``               -> SimpleCNN on the HIP path (simple_cnn.py: BatchNorm2d / Dropout2d / residual kernels
+                                       around the same fp16x3 convolutions; BASELINE configs[0]).
 
     Differences from the reference, both deliberate: for ``unet_convlstm_attention`` ``in_ch`` is
     ``cfg.model.in_ch`` when present, else ``len(cfg.data.input_vars)`` (the reference hard-codes 7, which cannot run
@@ -293,7 +294,7 @@ def get_model(cfg):
     if mtype == "unet":
         return UNet(in_ch=n_in, out_ch=n_out, base=int(cfg.model.base_channels))
     if mtype == "SimpleCNN":
-        from .host_models import SimpleCNN
+        from .simple_cnn import SimpleCNN
         kwargs = {k: v for k, v in _items(cfg.model) if k != "type"}      # src/models.py:9-13
         return SimpleCNN(n_input_channels=n_in, n_output_channels=n_out, **kwargs)
     if mtype == "cnn_transformer":

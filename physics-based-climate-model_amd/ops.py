@@ -541,6 +541,64 @@ def gates_bwd(dout, a2, s, z, pooled, gate, fmap, w1, w2, w7, dw1, dw2, dw7, def
     return dmap, (umax, cnt), dpool
 
 
+# ----------------------------------------------------------------------------------------------------- fused tail
+BLOCK_TAIL = os.environ.get("CM_BLOCK_TAIL", "1") != "0"      # sample-resident ConvBlock tail (csrc/block_tail.hip)
+
+
+def block_tail_supported(c, cr, h, w):
+    return BLOCK_TAIL and bool(lib.cm_block_tail_supported(c, cr, h, w))
+
+
+def block_tail_fwd(y2, gamma, beta, w1, w2, w7, pool_out=False, parts=None):
+    """GroupNorm+SiLU -> SE -> spatial gate (-> MaxPool2d(2)) of one ConvBlock in one launch (cm_block_tail_fwd).
+    ``parts`` = (stack, k) from conv3x3_parts instead of y2.  Returns (y2, stats, pooled, z, s, fmap, gate, out, mp);
+    the activation a2 is not materialised (gn_silu_apply(y2, gamma, beta, stats) reproduces it)."""
+    if parts is not None:
+        pt, k = parts
+        _, n, c, h, w = pt.shape
+        y2 = torch.empty(n, c, h, w, device=pt.device, dtype=torch.float32)
+    else:
+        n, c, h, w = _contig(y2).shape
+    dev = y2.device
+    cr = w1.shape[0]
+    stats = torch.empty(n * GN_GROUPS * 2, device=dev, dtype=torch.float32)
+    pooled = torch.empty(n, c, device=dev, dtype=torch.float32)
+    z = torch.empty(n, cr, device=dev, dtype=torch.float32)
+    s = torch.empty(n, c, device=dev, dtype=torch.float32)
+    fmap = torch.empty(n, 2, h, w, device=dev, dtype=torch.float32)
+    gate = torch.empty(n, h, w, device=dev, dtype=torch.float32)
+    out = torch.empty(n, c, h, w, device=dev, dtype=torch.float32)
+    mp = torch.empty(n, c, h // 2, w // 2, device=dev, dtype=torch.float32) if pool_out else None
+    if parts is not None:
+        check(lib.cm_block_tail_fwd(None, _p(pt), pt.stride(0), k, _p(y2), _p(gamma), _p(beta), _p(_contig(w1)),
+                                    _p(_contig(w2)), _p(_contig(w7)), _p(stats), _p(pooled), _p(z), _p(s), _p(fmap),
+                                    _p(gate), _p(out), _p(mp), n, c, cr, h, w, GN_EPS, _stream()), "block_tail_fwd")
+    else:
+        check(lib.cm_block_tail_fwd(_p(y2), None, 0, 0, None, _p(gamma), _p(beta), _p(_contig(w1)), _p(_contig(w2)),
+                                    _p(_contig(w7)), _p(stats), _p(pooled), _p(z), _p(s), _p(fmap), _p(gate), _p(out),
+                                    _p(mp), n, c, cr, h, w, GN_EPS, _stream()), "block_tail_fwd")
+    return y2, stats, pooled, z, s, fmap, gate, out, mp
+
+
+def block_tail_bwd(dout, y2, stats, gamma, beta, s, z, gate, fmap, w1, w2, w7, dw7):
+    """Whole-sample reductions of the tail's backward in one launch (cm_block_tail_bwd): returns dmap, (umax, cnt),
+    dpool, (dsig, dz) -- the tuple gates_bwd(..., defer_se_wgrad=True) returns."""
+    n, c, h, w = y2.shape
+    cr = w1.shape[0]
+    dev = y2.device
+    dmap = torch.empty(n, 2, h, w, device=dev, dtype=torch.float32)
+    umax = torch.empty(n, h, w, device=dev, dtype=torch.float32)
+    cnt = torch.empty(n, h, w, device=dev, dtype=torch.float32)
+    dpool = torch.empty(n, c, device=dev, dtype=torch.float32)
+    dsig = torch.empty(n, c, device=dev, dtype=torch.float32)
+    dz = torch.empty(n, cr, device=dev, dtype=torch.float32)
+    check(lib.cm_block_tail_bwd(_p(_contig(y2)), _p(stats), _p(gamma), _p(beta), _p(s), _p(z), _p(gate), _p(fmap),
+                                _p(_contig(w1)), _p(_contig(w2)), _p(_contig(w7)), _p(_contig(dout)), _p(dmap),
+                                _p(umax), _p(cnt), _p(dpool), _p(dsig), _p(dz), _p(dw7), n, c, cr, h, w, _stream()),
+          "block_tail_bwd")
+    return dmap, (umax, cnt), dpool, (dsig, dz)
+
+
 # ----------------------------------------------------------------------------------------------------- pool / skip
 def maxpool2_fwd(x):
     n, c, h, w = x.shape

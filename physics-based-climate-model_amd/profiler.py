@@ -5,8 +5,23 @@ launchers receive), immediately before and after the launch.  Algorithmic flops 
 arguments, not from counters.
 """
 import collections
+import contextlib
 
 import torch
+
+# Call-site tag of the launches being enqueued (set by the engine around the ConvLSTM cell, ...): lets bench.py report a
+# roofline for a PART of the step (north_star: "the ConvLSTM cell") made of several launcher families.
+REGION = None
+
+
+@contextlib.contextmanager
+def region(name):
+    global REGION
+    prev, REGION = REGION, name
+    try:
+        yield
+    finally:
+        REGION = prev
 
 
 def _conv_flops(a):        # cm_conv3x3(in0, st0, c0, in1, st1, c1, wp, bias, resid, st_resid, out, st_out, n, h, w, cout, ..)
@@ -104,7 +119,7 @@ class KernelTimer:
             rc = fn(*a)
             e1.record(st)
             fl, by = MODELS.get(name, (None, None))
-            self.records.append((name, e0, e1, fl(a) if fl else 0.0, by(a) if by else 0.0))
+            self.records.append((name, e0, e1, fl(a) if fl else 0.0, by(a) if by else 0.0, REGION))
             return rc
         return timed
 
@@ -121,10 +136,22 @@ class KernelTimer:
     def summary(self):
         torch.cuda.synchronize()
         out = collections.OrderedDict()
-        for name, e0, e1, fl, by in self.records:
+        for name, e0, e1, fl, by, _reg in self.records:
             d = out.setdefault(name, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
             d["calls"] += 1
             d["ms"] += e0.elapsed_time(e1)
             d["flops"] += fl
             d["bytes"] += by
+        return out
+
+    def by_region(self):
+        """{region: dict(calls, ms)} over the tagged launches (profiler.region)."""
+        torch.cuda.synchronize()
+        out = collections.OrderedDict()
+        for name, e0, e1, fl, by, reg in self.records:
+            if reg is None:
+                continue
+            d = out.setdefault(reg, dict(calls=0, ms=0.0))
+            d["calls"] += 1
+            d["ms"] += e0.elapsed_time(e1)
         return out

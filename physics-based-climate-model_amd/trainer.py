@@ -83,10 +83,15 @@ class HotPathTrainer:
                 raise ValueError("micro_batches must be 1 or 2")
             if n == 2 and x.shape[0] % 2:
                 raise ValueError(f"micro_batches=2 needs an even batch, got {x.shape[0]}")
+            if n == 2 and getattr(self.model, "batch_coupled", False):
+                raise ValueError("micro_batches=2 would change the model: its BatchNorm statistics run over the batch")
+            if n == 2 and self.use_graph and (engine.OVERLAP_WGRAD or engine.OVERLAP_LSTM) and not engine.PREFORK_OK:
+                raise ValueError("two micro-batches + side-stream overlap under graph capture needs the pre-forked "
+                                 "stream topology (engine.PREFORK_OK): a second-level fork crashes hipStreamEndCapture "
+                                 "(profiles/r03/capture_fork_probe.txt)")
             return n
-        from . import engine as _e
         B = x.shape[0]
-        if B % 2 or B < 4 or _e.OVERLAP_WGRAD or _e.OVERLAP_LSTM:
+        if B % 2 or B < 4:
             return 1
         kind = type(self.model).__name__
         if kind == "AttUNetConvLSTM" and x.dim() == 5:
@@ -108,11 +113,21 @@ class HotPathTrainer:
             fn(1)
             return
         main = torch.cuda.current_stream()
+        # Side streams of the halves (weight gradients / work beside the ConvLSTM chain, off by default): they must enter
+        # a graph capture as FIRST-level forks of the origin stream and join it directly -- a stream that enters from the
+        # second half's stream crashes hipStreamEndCapture (engine.PREFORK_OK, profiles/r03/capture_fork_probe.txt).
+        children = []
+        if engine.PREFORK_OK and (engine.OVERLAP_WGRAD or engine.OVERLAP_LSTM):
+            children = [engine._SideStream.child_of(self.device, st) for st in (main, self._side)]
+            for c in children:
+                c.wait_stream(main)
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
             fn(1)
         fn(0)
         main.wait_stream(self._side)
+        for c in children:
+            main.wait_stream(c)
 
     def _fwd_bwd(self, x, y, phase=None, overlap=True):
         """phase None: the whole {zero, pack, forward, loss, backward}; "early": up to and including the decoder /
@@ -204,8 +219,10 @@ class HotPathTrainer:
         self._adam()
 
     # ------------------------------------------------------------------ public
-    def step(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
-        """One optimisation step on batch (x [B,T,C,H,W], y [B,out,H,W]); returns the (device) loss tensor [1]."""
+    def step(self, x: torch.Tensor, y: torch.Tensor, exchange: bool = True) -> torch.Tensor:
+        """One optimisation step on batch (x [B,T,C,H,W], y [B,out,H,W]); returns the (device) loss tensor [1].
+        ``exchange=False`` (graph mode, measurement only): replay the same graphs WITHOUT the gradient all-reduces -- the
+        step then trains on the local gradients, which lets bench.py time the exchange's exposed share."""
         if not (x.is_cuda and y.is_cuda):
             raise RuntimeError("batch must be on the GPU")
         x = x.contiguous()
@@ -215,9 +232,12 @@ class HotPathTrainer:
             self._eager_step(x, y)
             return self.loss
         key = (tuple(x.shape), tuple(y.shape))
-        if key not in self._graphs:
-            self._capture(key, x, y)
+        # train / eval (dropout, BatchNorm mode) is baked into a capture: a graph recorded in the other mode is not reused
+        gkey = key + (bool(self.model.training), float(getattr(self.model, "dropout_p", 0.0)))
+        if gkey not in self._graphs:
+            self._capture(gkey, x, y)
         sx, sy = self._static[key]
+        key = gkey
         if x.data_ptr() != sx.data_ptr():          # a loader may write straight into input_buffers() and skip this copy
             sx.copy_(x, non_blocking=True)
         if y.data_ptr() != sy.data_ptr():
@@ -225,12 +245,14 @@ class HotPathTrainer:
         g1, g2, g3 = self._graphs[key]
         g1.replay()
         if g3 is not None:                         # distributed, two buckets: exchange 1 runs beside graph 2
-            w = self._exchange_early()
+            w = self._exchange_early() if exchange else None
             g2.replay()
-            self._exchange_late(w)
+            if exchange:
+                self._exchange_late(w)
             g3.replay()
         elif g2 is not None:                       # distributed, one bucket: gradient exchange between the two graphs
-            ddp.allreduce_gradients(self.grad)
+            if exchange:
+                ddp.allreduce_gradients(self.grad)
             g2.replay()
         return self.loss
 
@@ -262,8 +284,27 @@ class HotPathTrainer:
         self._graphs.clear()
 
     def state_dict(self) -> dict:
+        """{model, optimizer (torch.optim.Adam layout), steps, dropout_rng}.  ``dropout_rng`` = the {seed, counter} pair of
+        the counter-based dropout (cnn_transformer, SimpleCNN), so that a resumed run draws the masks the uninterrupted
+        run would have drawn.  (Lightning's own checkpoint container -- ``state_dict`` under a ``model.`` prefix,
+        ``optimizer_states`` -- is ``to_lightning_checkpoint`` / ``from_lightning_checkpoint`` below.)"""
+        rng = self.model.__dict__.get("_rng")
         return {"model": {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},
-                "optimizer": self.optimizer_state_dict(), "steps": self.steps}
+                "optimizer": self.optimizer_state_dict(), "steps": self.steps,
+                "dropout_rng": None if rng is None else [int(v) for v in rng.cpu().tolist()]}
+
+    def to_lightning_checkpoint(self) -> dict:
+        """The keys of a Lightning checkpoint the reference resumes from with ``ckpt_path=`` (main_final.py:770-774):
+        ``state_dict`` with the LightningModule's ``model.`` prefix, ``optimizer_states`` (one torch.optim.Adam state),
+        ``global_step``."""
+        sd = self.state_dict()
+        return {"state_dict": {"model." + k: v for k, v in sd["model"].items()}, "optimizer_states": [sd["optimizer"]],
+                "global_step": sd["steps"], "epoch": 0, "dropout_rng": sd["dropout_rng"]}
+
+    def from_lightning_checkpoint(self, ck: dict) -> None:
+        self.load_state_dict({"model": {k[len("model."):]: v for k, v in ck["state_dict"].items() if k.startswith("model.")},
+                              "optimizer": ck["optimizer_states"][0], "steps": int(ck.get("global_step", 0)),
+                              "dropout_rng": ck.get("dropout_rng")})
 
     def load_state_dict(self, sd: dict) -> None:
         own = self.model.state_dict()
@@ -272,6 +313,9 @@ class HotPathTrainer:
                 own[k].copy_(v)                      # in place: the flat parameter buffer keeps its address
         self.load_optimizer_state_dict(sd["optimizer"])
         self.steps = int(sd.get("steps", 0))
+        rng = sd.get("dropout_rng")
+        if rng is not None and hasattr(self.model, "reseed_dropout"):
+            self.model.reseed_dropout(int(rng[0]), int(rng[1]))
 
     def input_buffers(self, x_shape, y_shape):
         """The static device buffers the replayed graph reads for this batch shape (allocated on first use).  A data
@@ -286,12 +330,15 @@ class HotPathTrainer:
     def _capture(self, key, x, y):
         """Record {fwd, loss, bwd} and {Adam} as two hipGraphs with the RCCL all-reduce between them, or -- on one
         GPU -- the whole step as a single graph."""
-        sx, sy = self.input_buffers(x.shape, y.shape)
+        sx, sy = self.input_buffers(x.shape, y.shape)      # (key = shapes + mode; the buffers are per shape)
         if x.data_ptr() != sx.data_ptr():
             sx.copy_(x)
         if y.data_ptr() != sy.data_ptr():
             sy.copy_(y)
-        # warm-up on a side stream (lazy module loading, allocator pools) WITHOUT touching the optimizer state
+        # warm-up on a side stream (lazy module loading, allocator pools) WITHOUT touching the optimizer state -- nor the
+        # model's own forward-side state (BatchNorm running buffers, dropout counters): snapshot and restore it
+        snap = getattr(self.model, "_state_snapshot", None)
+        state = snap() if snap is not None else None
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -300,6 +347,8 @@ class HotPathTrainer:
             self._fwd_bwd(sx, sy, overlap=False)   # builds the pruned pack table (cannot be built during capture)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        if state is not None:
+            self.model._state_restore(state)
         g1 = torch.cuda.CUDAGraph()
         g2 = g3 = None
         if self._bucketed():
@@ -374,7 +423,7 @@ class InferenceRunner:
         x = x.contiguous()
         if not self.use_graph:
             return self._fwd(x)
-        key = tuple(x.shape)
+        key = tuple(x.shape) + (bool(self.model.training), float(getattr(self.model, "dropout_p", 0.0)))
         if key not in self._graphs:
             sx = torch.empty_like(x)
             sx.copy_(x)

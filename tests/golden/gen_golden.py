@@ -308,10 +308,22 @@ def main():
     net.train()
     torch.manual_seed(7)               # Dropout2d mask stream
     xg = x.clone().requires_grad_()
+    seen = {}
+    hook = net.dropout.register_forward_hook(lambda m, i, o: seen.__setitem__("in_out", (i[0].detach(), o.detach())))
     y_train = net(xg); y_train.square().mean().backward()
+    hook.remove()
+    # the per-(sample, channel) multipliers Dropout2d drew (0 or 1/(1-p)): read off a plane's largest-|input| element
+    di, do = seen["in_out"]
+    flat_i, flat_o = di.flatten(2), do.flatten(2)
+    idx = flat_i.abs().argmax(-1, keepdim=True)
+    kept = (flat_o.gather(-1, idx) != 0).squeeze(-1)
+    drop_mask = torch.where(kept, torch.tensor(1.0 / (1.0 - 0.2)), torch.tensor(0.0)).float()
+    assert torch.allclose(di * drop_mask[:, :, None, None], do, rtol=1e-6, atol=0)
+    extra = {"g." + k: p_.grad for k, p_ in net.named_parameters()}
+    extra.update({"b." + k: v for k, v in net.state_dict().items() if "running_" in k})      # buffers AFTER the train step
     npz("simple_cnn.npz", names=np.array(names), shapes=np.stack(shapes_), sums=np.array(sums), x=x, y_eval=y_eval,
         y_train=y_train, dx_train=xg.grad, g_initial0=net.initial[0].weight.grad,
-        bn_running_mean=net.initial[1].running_mean)
+        bn_running_mean=net.initial[1].running_mean, drop_mask=drop_mask, **extra)
     # factory smoke: default YAML values of configs/model/SimpleCNN.yaml (10.73 M parameters)
     net = mods.SimpleCNN(n_input_channels=5, n_output_channels=2, kernel_size=3, init_dim=64, depth=4, dropout_rate=0.2)
     npz("simple_cnn_default_cfg.npz", n_params=np.array(sum(p_.numel() for p_ in net.parameters())),

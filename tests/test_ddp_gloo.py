@@ -75,3 +75,46 @@ def test_shard_batch_rejects_ragged():
     from climate_amd import ddp
     with pytest.raises(ValueError):
         ddp.shard_batch(33, 0, 2)
+
+
+def _worker8(rank, world, port, ret):
+    """World 8 on the CPU: the per-rank batch shares of BASELINE configs 3 / 5 and the trainer's two-bucket exchange at the
+    REAL bucket boundary of the model's flat gradient buffer (encoder prefix / ConvLSTM + decoder + head suffix), with the
+    never-communicated post_conv tail behind it."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from climate_amd import ddp
+    from climate_amd.model import AttUNetConvLSTM
+    ddp.init_from_env(backend="gloo")
+    # config 3: global batch 256 -> 32 per rank; config 5: 128 -> 16
+    for glob, per in ((256, 32), (128, 16)):
+        sl = ddp.shard_batch(glob, rank, world)
+        assert (sl.start, sl.stop) == (rank * per, (rank + 1) * per)
+    torch.manual_seed(0)
+    m = AttUNetConvLSTM(5, 2, 8, 3)                     # CPU construction: layout only, nothing is launched
+    lay = m._build_layout()
+    nt, bb = m.n_flat_trainable, m.bucket_boundary
+    assert 0 < bb < nt and bb % 64 == 0
+    assert all(o + k <= bb for n, (o, k, _) in lay.items() if n.startswith("enc"))
+    assert all(o >= bb for n, (o, k, _) in lay.items() if not n.startswith("enc"))
+    assert all(o >= nt for n, (o, k, _) in lay.items() if n.startswith("post_conv."))       # outside the exchange
+    total = max(o + k for o, k, _ in lay.values())
+    gen = torch.Generator().manual_seed(3)
+    gfull = torch.randn(world, total, generator=gen)
+    g = gfull[rank].clone()
+    _, work = ddp.allreduce_gradients(g[bb:nt], async_op=True)      # suffix first, asynchronously (beside the encoder backward)
+    ddp.allreduce_gradients(g[:bb])
+    work.wait()
+    assert torch.allclose(g[:nt], gfull[:, :nt].sum(0), atol=1e-5)
+    assert torch.equal(g[nt:], gfull[rank, nt:])                    # the post_conv tail never travels
+    ret[rank] = True
+    dist.destroy_process_group()
+
+
+def test_gradient_exchange_world8_buckets():
+    world = 8
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker8, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world))

@@ -77,3 +77,65 @@ def test_two_ranks_match_single_process(tmp_path, backend):
     want = m.state_dict()
     for k in want:
         assert rel_l2(got[k], want[k]) < 2e-6, k
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE config 2 size
+CFG2 = dict(in_ch=5, out_ch=2, base=32, T=6, B=64, H=48, W=72)       # 32 per rank = BASELINE configs[1]'s per-GPU batch
+
+
+def _batch2():
+    g = torch.Generator("cpu").manual_seed(21)
+    x = torch.randn(CFG2["B"], CFG2["T"], CFG2["in_ch"], CFG2["H"], CFG2["W"], generator=g)
+    y = torch.randn(CFG2["B"], CFG2["out_ch"], CFG2["H"], CFG2["W"], generator=g)
+    return x, y
+
+
+def _model2():
+    from climate_amd.model import AttUNetConvLSTM
+    torch.manual_seed(42)
+    return AttUNetConvLSTM(CFG2["in_ch"], CFG2["out_ch"], CFG2["base"], CFG2["T"]).cuda()
+
+
+def _worker2(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from climate_amd import ddp
+    from climate_amd.trainer import HotPathTrainer
+    ddp.init_from_env(backend="gloo")
+    torch.cuda.set_device(0)
+    m = _model2()
+    tr = HotPathTrainer(m, lr=5e-4, use_graph=True)            # hipGraphs on BOTH ranks: three graphs, two buckets
+    x, y = _batch2()
+    sl = ddp.shard_batch(CFG2["B"], rank, world)
+    xs, ys = x[sl].cuda(), y[sl].cuda()
+    losses = [tr.step(xs, ys).item() for _ in range(3)]
+    assert tr._parts == 2 and tr._bucketed()                    # two micro-batches per rank under the bucketed exchange
+    torch.cuda.synchronize()
+    torch.save({"sd": {k: v.cpu() for k, v in m.state_dict().items()}, "loss": losses}, out_path + f".{rank}")
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_config2_graphs_on_both_ranks(tmp_path):
+    """The first multi-rank run of the benchmark's own schedule: BASELINE configs[1] per-rank shape (32 x 6 frames, base
+    32), hipGraphs on both ranks, two micro-batches per rank, two-bucket exchange (gloo; the ranks share the one GPU).
+    Parameters after three steps == the single-process step on the 64-sample batch; the ranks agree bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from climate_amd.trainer import HotPathTrainer
+    out_path = str(tmp_path / "rank")
+    mp.spawn(_worker2, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    r0 = torch.load(out_path + ".0", weights_only=True)
+    r1 = torch.load(out_path + ".1", weights_only=True)
+    for k in r0["sd"]:
+        assert torch.equal(r0["sd"][k], r1["sd"][k]), k         # same reduced gradients, same Adam: identical replicas
+    m = _model2()
+    tr = HotPathTrainer(m, lr=5e-4, use_graph=False, distributed=False, micro_batches=1)
+    x, y = _batch2()
+    losses = [tr.step(x.cuda(), y.cuda()).item() for _ in range(3)]
+    # the global loss is the mean of the two ranks' (equal-sized shards)
+    for a, b0, b1 in zip(losses, r0["loss"], r1["loss"]):
+        assert abs(a - 0.5 * (b0 + b1)) < 2e-5 * abs(a)
+    want = m.state_dict()
+    for k in want:
+        assert rel_l2(r0["sd"][k], want[k]) < 2e-5, k

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import oracle
-from conftest import load_golden
+from conftest import load_golden, rel_l2
 
 
 def test_cabi_library_exports_every_declared_symbol():
@@ -111,10 +111,10 @@ def test_factory_and_config_surface():
 
 def test_factory_serves_every_reference_model_type():
     """src/models.py:7-38 dispatches on four model.type values; replacing the reference's factory must not break any
-    of them (SimpleCNN = BASELINE configs[0], stock torch; unet = the same HIP kernels on one frame)."""
+    of them (SimpleCNN = BASELINE configs[0], on the HIP path since round 3; unet = the same HIP kernels on one frame)."""
     import climate_amd
     from climate_amd.config import load_config
-    from climate_amd.host_models import SimpleCNN
+    from climate_amd.simple_cnn import SimpleCNN
     from climate_amd.model import UNet, get_model
     cdir = os.path.join(climate_amd._PKG_DIR, "configs")
     g = load_golden("simple_cnn_default_cfg.npz")
@@ -122,8 +122,8 @@ def test_factory_serves_every_reference_model_type():
     assert isinstance(m, SimpleCNN)
     assert sum(p.numel() for p in m.parameters()) == int(g["n_params"]) == 10730626
     assert list(m.state_dict()) == g["names"].tolist()
-    y = m.eval()(torch.zeros(2, 5, 16, 24))                                            # plumbing: runs on the CPU
-    assert y.shape == (2, 2, 16, 24)
+    with pytest.raises(RuntimeError, match="HIP path only"):                           # no CPU fallback
+        m.eval()(torch.zeros(2, 5, 16, 24))
     u = get_model(load_config(cdir, overrides=["model=unet", "model.base_channels=8"]))
     assert isinstance(u, UNet) and u.base == 8
     want = oracle.unet_param_shapes(5, 2, 8)
@@ -135,32 +135,31 @@ def test_factory_serves_every_reference_model_type():
 
 
 def test_cnn_transformer_matches_reference():
-    """model.type = cnn_transformer (src/cnn_transformer.py:4-54; BASELINE configs[3]): same state_dict, default init
-    under a seed, eval forward and gradients as the reference -- for the stock-torch restatement (host_models) and, as
-    far as a CPU can see (names, shapes, initial values, constructor checks), for the HIP module ``get_model`` serves."""
+    """model.type = cnn_transformer (src/cnn_transformer.py:4-54; BASELINE configs[3]): the HIP module ``get_model``
+    serves has the reference's state_dict and default init under a seed (as far as a CPU can see: names, shapes, initial
+    values, constructor checks), and the CPU oracle reproduces the reference's eval forward and gradients."""
     import climate_amd
     from climate_amd.config import load_config
-    from climate_amd.host_models import CNNTransformer
     from climate_amd.model import get_model
     g = load_golden("cnn_transformer_tiny.npz")
     torch.manual_seed(42)
-    m = CNNTransformer(in_channels=5, out_channels=2, embed_dim=32, depth=2, n_heads=4, mlp_dim=48, dropout=0.1)
+    from climate_amd.cnn_transformer import CNNTransformer as HipCNNTransformer
+    m = HipCNNTransformer(in_channels=5, out_channels=2, embed_dim=32, depth=2, n_heads=4, mlp_dim=48, dropout=0.1)
     sd = m.state_dict()
     assert list(sd) == g["names"].tolist()
     for k, sm in zip(g["names"].tolist(), g["sums"].tolist()):
         assert abs(sd[k].double().sum().item() - sm) < 1e-9, k
-    m.eval()
+    P = {k: v.detach().clone().requires_grad_() for k, v in sd.items()}
     x = g["x"].clone().requires_grad_()
-    y = m(x); y.square().mean().backward()
+    y = oracle.cnn_transformer_forward(P, x, 4); y.square().mean().backward()
     assert torch.allclose(y, g["y_eval"], rtol=0, atol=2e-6)
     assert torch.allclose(x.grad, g["dx"], rtol=1e-4, atol=1e-8)
-    assert torch.allclose(m.pos_embedding.grad, g["g_pos"], rtol=1e-4, atol=1e-8)
-    assert torch.allclose(m.transformer.layers[0].self_attn.in_proj_weight.grad, g["g_inproj0"], rtol=1e-4, atol=1e-8)
+    assert torch.allclose(P["pos_embedding"].grad, g["g_pos"], rtol=1e-4, atol=1e-8)
+    assert torch.allclose(P["transformer.layers.0.self_attn.in_proj_weight"].grad, g["g_inproj0"], rtol=1e-4, atol=1e-8)
     big = get_model(load_config(os.path.join(climate_amd._PKG_DIR, "configs"),
                                 overrides=["model=cnn_transformer", "model.embed_dim=256", "model.depth=6",
                                            "model.n_heads=8"]))
     c4 = load_golden("cnn_transformer_cfg4.npz")
-    from climate_amd.cnn_transformer import CNNTransformer as HipCNNTransformer
     assert isinstance(big, HipCNNTransformer) and list(big.state_dict()) == c4["names"].tolist()
     assert sum(p.numel() for p in big.parameters()) == int(c4["n_params"]) == 2895170          # BASELINE.md section 2
     with pytest.raises(RuntimeError, match="HIP path only"):
@@ -176,9 +175,10 @@ def test_cnn_transformer_matches_reference():
 
 
 def test_simple_cnn_matches_reference():
-    """Stock-torch SimpleCNN restatement vs the reference's (src/models.py:44-123): default init under a seed, eval
-    forward, train-mode forward/backward (BatchNorm batch statistics + the Dropout2d mask stream)."""
-    from climate_amd.host_models import SimpleCNN
+    """SimpleCNN (src/models.py:44-123) against the fixture generated from the reference: the HIP module has the reference's
+    state_dict and default init under a seed; the CPU oracle reproduces the eval forward, the train-mode forward / backward
+    (BatchNorm batch statistics, the Dropout2d multipliers the reference drew) and the running-buffer updates."""
+    from climate_amd.simple_cnn import SimpleCNN
     g = load_golden("simple_cnn.npz")
     torch.manual_seed(42)
     m = SimpleCNN(n_input_channels=5, n_output_channels=2, kernel_size=3, init_dim=8, depth=3, dropout_rate=0.2)
@@ -187,17 +187,22 @@ def test_simple_cnn_matches_reference():
     for k, shp, sm in zip(g["names"].tolist(), g["shapes"], g["sums"].tolist()):
         assert tuple(sd[k].shape) == tuple(int(v) for v in shp[:sd[k].dim()])
         assert abs(sd[k].double().sum().item() - sm) < 1e-9, k
+    assert m._grad_names == [n for n, _ in m.named_parameters()]                     # every parameter is trained
+    P = {k: v.detach().clone().requires_grad_() for k, v in m.named_parameters()}
+    B = {k: v.detach().clone() for k, v in m.named_buffers()}
     x = g["x"]
-    m.eval()
-    assert torch.allclose(m(x), g["y_eval"], rtol=0, atol=1e-6)
-    m.train()
-    torch.manual_seed(7)
+    assert torch.allclose(oracle.simple_cnn_forward(P, B, x, training=False), g["y_eval"], rtol=0, atol=1e-6)
     xg = x.clone().requires_grad_()
-    y = m(xg); y.square().mean().backward()
+    y = oracle.simple_cnn_forward(P, B, xg, training=True, drop_mask=g["drop_mask"]); y.square().mean().backward()
     assert torch.allclose(y, g["y_train"], rtol=0, atol=1e-6)
     assert torch.allclose(xg.grad, g["dx_train"], rtol=1e-5, atol=1e-7)
-    assert torch.allclose(m.initial[0].weight.grad, g["g_initial0"], rtol=1e-5, atol=1e-7)
-    assert torch.allclose(m.initial[1].running_mean, g["bn_running_mean"], rtol=0, atol=1e-7)
+    for k in P:
+        assert rel_l2(P[k].grad, g["g." + k]) < 1e-5 or g["g." + k].abs().max() < 1e-6, k
+    for k in B:
+        if "running_" in k:
+            assert torch.allclose(B[k], g["b." + k], rtol=1e-6, atol=1e-7), k
+    with pytest.raises(ValueError, match="kernel_size"):
+        SimpleCNN(5, 2, kernel_size=5)
 
 
 def test_hip_adam_state_interoperates_with_torch_adam():

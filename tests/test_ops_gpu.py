@@ -342,6 +342,98 @@ def test_fused_se_stats_equals_separate_launches(ops, shape):
     assert rel_l2(out1, ref) < TOL
 
 
+TAIL_SHAPES = [(5, 64, 24, 36), (7, 128, 12, 18), (6, 256, 6, 9), (3, 16, 8, 12), (4, 8, 6, 4), (2, 256, 12, 18),
+               (3, 512, 6, 9), (96, 64, 24, 36), (2, 24, 4, 6)]
+
+
+@pytest.mark.parametrize("shape", TAIL_SHAPES)
+def test_block_tail_equals_launch_chain(ops, shape):
+    """Sample-resident ConvBlock tail (cm_block_tail_fwd / _bwd, one workgroup per sample) against the launch chain it
+    replaces (cm_gn_silu_fwd -> cm_se_spatial_stats -> cm_spatial_apply; cm_gate_bwd_reduce -> cm_conv7_bwd ->
+    cm_se_bwd_reduce -> cm_se_excite_bwd): statistics, squeeze, SE scale, maps, gate, output, pooled output, and every
+    backward map; the recomputed activation must equal the chain's stored one BIT FOR BIT given the same statistics."""
+    n, c, h, w = shape
+    cr = max(1, c // 8)
+    assert ops.block_tail_supported(c, cr, h, w), "shape expected on the sample-resident path"
+    torch.manual_seed(11)
+    y2 = torch.randn(n, c, h, w, device="cuda") * 1.7 + 0.3
+    y2[0, :, : h // 2] = 0.0                       # a constant region (left-padded frames produce them)
+    gamma = torch.randn(c, device="cuda") * 0.3 + 1.0
+    beta = torch.randn(c, device="cuda") * 0.2
+    w1 = torch.randn(cr, c, 1, 1, device="cuda") * 0.3
+    w2 = torch.randn(c, cr, 1, 1, device="cuda") * 0.3
+    w7 = torch.randn(1, 2, 7, 7, device="cuda") * 0.1
+    pool = h % 2 == 0 and w % 2 == 0
+    # chain
+    a2, st, pooled = ops.gn_silu_fwd(y2, gamma, beta, want_pooled=True)
+    res = ops.se_spatial_gate_fwd(a2, pooled, w1, w2, w7, pool_out=pool)
+    out0, z0, s0, fmap0, gate0 = res[:5]
+    # tail
+    y2b, st1, pooled1, z1, s1, fmap1, gate1, out1, mp1 = ops.block_tail_fwd(y2, gamma, beta, w1, w2, w7, pool_out=pool)
+    assert y2b.data_ptr() == y2.data_ptr()
+    assert rel_l2(st1, st) < 1e-6
+    assert rel_l2(pooled1, pooled) < 1e-5 and rel_l2(z1, z0) < 1e-5 and rel_l2(s1, s0) < 1e-6
+    assert rel_l2(fmap1, fmap0) < 1e-5 and rel_l2(gate1, gate0) < 1e-6 and rel_l2(out1, out0) < 1e-5
+    if pool:
+        assert torch.equal(mp1, F.max_pool2d(out1, 2))
+    # self-consistency, bit for bit: out == (a2 * s) * gate and map == [mean, max](a2 * s) with a2 RECOMPUTED from the stored
+    # statistics -- what the backward kernels rely on
+    a2r = ops.gn_silu_apply(y2, gamma, beta, st1)
+    u = a2r * s1[:, :, None, None]
+    assert torch.equal(out1, u * gate1[:, None])
+    assert torch.equal(fmap1[:, 1], u.amax(1))
+    # float64 reference of the whole tail
+    yd = y2.double().cpu()
+    ad = F.silu(F.group_norm(yd, 8, gamma.double().cpu(), beta.double().cpu(), 1e-5))
+    sd = torch.sigmoid(F.conv2d(F.relu(F.conv2d(ad.mean((2, 3), keepdim=True), w1.double().cpu())), w2.double().cpu()))
+    ud = ad * sd
+    md = torch.cat([ud.mean(1, keepdim=True), ud.amax(1, keepdim=True)], 1)
+    ref = ud * torch.sigmoid(F.conv2d(md, w7.double().cpu(), padding=3))
+    assert rel_l2(out1, ref) < 2e-6
+    # partial-slices input: three slices that sum to y2
+    parts = torch.empty(4, n, c, h, w, device="cuda")
+    parts[0] = y2 * 0.5
+    parts[1] = y2 * 0.25
+    parts[2] = y2 - parts[0] - parts[1]
+    parts[3] = float("nan")                       # (not one of the k = 3 slices)
+    resp = ops.block_tail_fwd(None, gamma, beta, w1, w2, w7, pool_out=pool, parts=(parts, 3))
+    ysum = (parts[0] + parts[1]) + parts[2]
+    assert torch.equal(resp[0], ysum)
+    assert rel_l2(resp[7], out1) < 1e-5
+    # ---- backward ----
+    dout = torch.randn(n, c, h, w, device="cuda")
+    dw1 = torch.zeros_like(w1); dw2 = torch.zeros_like(w2); dw7a = torch.zeros_like(w7); dw7b = torch.zeros_like(w7)
+    # (chain fed with the TAIL's forward tensors so that both see identical operands)
+    dmap0, (umax0, cnt0), dpool0, (dsig0, dz0) = ops.gates_bwd(dout, a2r, s1, z1, pooled1, gate1, fmap1, w1, w2, w7, dw1,
+                                                               dw2, dw7a, defer_se_wgrad=True)
+    dmap1, (umax1, cnt1), dpool1, (dsig1, dz1) = ops.block_tail_bwd(dout, y2, st1, gamma, beta, s1, z1, gate1, fmap1, w1,
+                                                                   w2, w7, dw7b)
+    assert torch.equal(umax1, umax0) and torch.equal(cnt1, cnt0)
+    assert rel_l2(dmap1, dmap0) < 1e-5 and rel_l2(dw7b, dw7a) < 1e-5
+    assert rel_l2(dsig1, dsig0) < 1e-5 and rel_l2(dz1, dz0) < 1e-5 and rel_l2(dpool1, dpool0) < 1e-5
+
+
+def test_block_tail_ties(ops):
+    """amax ties through the sample-resident tail: all channels equal (count = C) and a constant (left-padded) sample."""
+    n, c, h, w = 3, 64, 12, 18
+    cr = 8
+    torch.manual_seed(5)
+    base = torch.randn(n, 1, h, w, device="cuda")
+    y2 = base.expand(n, c, h, w).contiguous()
+    y2[1] = 0.0
+    gamma = torch.ones(c, device="cuda"); beta = torch.zeros(c, device="cuda")
+    w1 = torch.zeros(cr, c, 1, 1, device="cuda"); w2 = torch.zeros(c, cr, 1, 1, device="cuda")     # s = 0.5 everywhere
+    w7 = torch.randn(1, 2, 7, 7, device="cuda") * 0.1
+    _, st, pooled, z, s, fmap, gate, out, _ = ops.block_tail_fwd(y2, gamma, beta, w1, w2, w7)
+    assert torch.all(s == 0.5)
+    dout = torch.randn(n, c, h, w, device="cuda")
+    dw7 = torch.zeros_like(w7)
+    dmap, (umax, cnt), dpool, _ = ops.block_tail_bwd(dout, y2, st, gamma, beta, s, z, gate, fmap, w1, w2, w7, dw7)
+    # every group of a sample holds identical channels -> identical normalised values -> all C channels tie
+    assert torch.all(cnt == c)
+    assert torch.equal(umax, fmap[:, 1])
+
+
 def test_conv7_bwd_many_workgroups(ops):
     """conv7 backward at the benchmark width (1152-row partial table + fold), accumulating over repeated launches."""
     torch.manual_seed(4)

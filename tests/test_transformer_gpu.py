@@ -374,7 +374,7 @@ def test_cnn_transformer_config4_width_vs_oracle(ops):
     opt = torch.optim.Adam([pa[k] for k in names], lr=5e-4)
     worst_g = worst_p = 0.0
     # The gradient is discontinuous in every ReLU's on/off decision, and ONE flipped unit of N moves a tensor by
-    # ~1/sqrt(N) in relative L2 (1.2e-3 in the decoder: tools/tf_badstate.py found exactly one pre-activation of 1e-8
+    # ~1/sqrt(N) in relative L2 (1.2e-3 in the decoder: a round-2 probe on a saved state found exactly one pre-activation of 1e-8
     # on the kink after two Adam steps, in one run out of three -- the trajectories differ at the 1e-7 level through
     # the order of float atomics).  So, as for amax / MaxPool on the hot path, the float64 oracle adopts the device's
     # decisions and validates each (|pre-activation| < 1e-5 rms where they differ): violations must be 0.

@@ -85,7 +85,7 @@ def main():
             e64 = stages(P, xin32, skip32, prefix, torch.float64)
             e32 = stages(P, xin32, skip32, prefix, torch.float32)
         outd, (ctx, _) = engine.up_fwd(p, pk, prefix, xin32.cuda(), skip32.cuda(), True)
-        devs = dict(u=ctx.x0, y1=ctx.y1, a1=ctx.a1, y2=ctx.y2, a2=ctx.a2, out=outd)
+        devs = dict(u=ctx.x0, y1=ctx.y1, a1=ctx.a1, y2=ctx.y2, a2=ctx.activation2(), out=outd)
         print(f"{prefix} on exact inputs, rel-L2 vs float64:   device     cpu-fp32    (y: also relative to the centred value)")
         for k in devs:
             extra = ""
