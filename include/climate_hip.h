@@ -273,6 +273,17 @@ int cm_lstm_gates_bwd(float* gates, long long sg, const float* c_prev, long long
                       long long scc, const float* dh_a, long long sa, const float* dh_b, long long sb, float* dc,
                       int first, int b, int ch, int hw, cm_stream stream);
 
+/* One ConvLSTM time step t >= 1 as ONE launch (csrc/lstm_step.hip): gates = x-projection [+ bias] (already in `gates`) +
+ * conv3x3(h_{t-1}, W_h) on the f16 matrix cores (fp16x3), then the stage above -- ConvLSTMCell.forward
+ * src/convlstm.py:11-19 without the x-part of its convolution (computed for all T at once).  wph / wscale_inv: the fp16x3
+ * operand of the weight's h-columns from cm_pack_conv3x3_h3_batch (k channels = ch, outputs = 4 ch).  hprev, c_prev,
+ * c_out, h_out are [b,ch,h*w] with their own sample strides; gates [b,4ch,h*w] is overwritten with i, f, o, g.
+ * cm_lstm_step_supported: ch in {64, 128, 256} and h*w <= 64 (the H/8 level of BASELINE configs 2 and 3). */
+int cm_lstm_step_supported(int b, int ch, int h, int w);
+int cm_lstm_step_fwd(const float* hprev, long long sh, const void* wph, const float* wscale_inv, float* gates,
+                     long long sg, const float* c_prev, long long scp, float* c_out, long long sco, float* h_out,
+                     long long sho, int b, int ch, int h, int w, cm_stream stream);
+
 /* The same two stages fed by a "partial slices" recurrent projection (cm_conv3x3_h3 config bit 29: the reduction shares
  * of the h-projection / its data gradient are STORED as nparts slices instead of being added with atomics -- the
  * recurrence is a chain of small launches whose cost is latency, and the atomics were half of it):

@@ -23,16 +23,23 @@ Tensor = torch.Tensor
 Params = Dict[str, Tensor]
 
 
+KEEP_ACTIVATION2 = False      # debugging / tests (HotPathTrainer.keep_saved sets it): see _BlockCtx.activation2
+
+
 class _BlockCtx:
     """Tensors one ConvBlock keeps for its backward.  ``a2`` (the activation entering the SE block) is None when the
     sample-resident tail ran: it is never stored there and ``activation2()`` recomputes it bit-exactly."""
     __slots__ = ("x0", "x1", "y1", "a1", "st1", "y2", "a2", "st2", "pooled", "z", "s", "fmap", "gate", "out", "be",
-                 "gn2")
+                 "gn2", "a2_dbg")
 
     def activation2(self):
-        """SiLU(GroupNorm(y2)), the stored tensor or its recomputation from the stored statistics (tests, probes)."""
+        """SiLU(GroupNorm(y2)): the stored tensor, the copy the forward made under KEEP_ACTIVATION2, or its recomputation
+        from the stored statistics (only valid while the GroupNorm parameters are the forward's: a fused trainer step
+        has already run Adam on them when it returns -- tests that look at a2 afterwards set KEEP_ACTIVATION2)."""
         if self.a2 is not None:
             return self.a2
+        if self.a2_dbg is not None:
+            return self.a2_dbg
         return ops.gn_silu_apply(self.y2, self.gn2[0], self.gn2[1], self.st2)
 
 
@@ -326,7 +333,7 @@ def _block_fwd(p: Params, pk, prefix: str, x0: Tensor, x1: Optional[Tensor], sav
     r2 = pk.conv_parts(prefix + "body.3.weight/f", a1, co, be_out=be[1]) if _small_launch(a1, co, co) else None
     g2, b2 = p[prefix + "body.4.weight"], p[prefix + "body.4.bias"]
     w1, w2, w7 = p[prefix + "se.fc.0.weight"], p[prefix + "se.fc.2.weight"], p[prefix + "spat.conv.weight"]
-    if ops.block_tail_supported(co, w1.shape[0], a1.shape[2], a1.shape[3]):
+    if ops.block_tail_supported(co, w1.shape[0], a1.shape[2], a1.shape[3], n=a1.shape[0]):
         # the whole tail in one launch, one workgroup per sample (csrc/block_tail.hip); a2 is not materialised
         y2 = None if r2 is not None else pk.conv(prefix + "body.3.weight/f", a1, co, be_out=be[1])
         y2, st2, pooled, z, s, fmap, gate, out, mp = ops.block_tail_fwd(y2, g2, b2, w1, w2, w7, pool_out=pool, parts=r2)
@@ -347,6 +354,8 @@ def _block_fwd(p: Params, pk, prefix: str, x0: Tensor, x1: Optional[Tensor], sav
         ctx.pooled, ctx.z, ctx.s, ctx.fmap, ctx.gate, ctx.out = pooled, z, s, fmap, gate, out
         ctx.be = be
         ctx.gn2 = (g2, b2)
+        # (tests / probes that inspect a2 after a whole trainer step: materialise it now, one extra launch per block)
+        ctx.a2_dbg = ops.gn_silu_apply(y2, g2, b2, st2) if (a2 is None and KEEP_ACTIVATION2) else None
     if pool:
         return out, ctx, mp
     return out, ctx
@@ -443,8 +452,35 @@ class _SideStream:
         with torch.cuda.stream(self.side):
             fn()
 
+    # the stream a graph capture started on while the trainer runs two micro-batches on two streams (trainer._run_parts)
+    origin: "Optional[torch.cuda.Stream]" = None
+
+    def deferred_join(self) -> bool:
+        """Under capture, a NON-origin stream that waits for its own child (fork + join between two forked streams)
+        crashes hipStreamEndCapture; fork-only edges are fine and so is a join into the origin (tools/capture_fork_probe.py,
+        profiles/r03/capture_fork_probe.txt).  In that situation the join is left to the origin (trainer._run_parts joins
+        every child directly), which is sufficient as long as nothing on the parent consumes the child's results first --
+        the weight-gradient unpack therefore runs ON the child (``run_last``)."""
+        o = _SideStream.origin
+        return (self.enabled and o is not None and torch.cuda.is_current_stream_capturing()
+                and self.main.cuda_stream != o.cuda_stream)
+
+    def run_last(self, fn):
+        """fn consumes what the side stream produced (the unpack of the staged weight gradients): run it behind that work
+        on the side stream when the join is deferred, on the parent after a normal join otherwise."""
+        if self.deferred_join():
+            with torch.cuda.stream(self.side):
+                fn()
+            self.keep.clear()
+        else:
+            self.join()
+            fn()
+
     def join(self):
         if self.enabled:
+            if self.deferred_join():
+                raise RuntimeError("a side-stream join inside the second micro-batch's stream cannot be captured "
+                                   "(hipStreamEndCapture crash, profiles/r03/capture_fork_probe.txt)")
             self.main.wait_stream(self.side)
         self.keep.clear()
 
@@ -512,8 +548,18 @@ def convlstm_fwd(p: Params, pk, s4: Tensor, B: int, T: int, save: bool = True, b
     call = torch.empty(B, T, ch, h8, w8, device=dev, dtype=torch.float32)
     bott = torch.empty(B, ch, h8, w8, device=dev, dtype=torch.float32)
     pbuf = None                     # slice stack of the partial-slices form, reused by every step
+    fused = "lstm.h/f" in pk.pkh and ops.lstm_step_supported(B, ch, h8, w8)
     for t in range(T):
         parts = None
+        if t > 0 and fused:
+            # projection + gates + state update of step t in ONE launch (csrc/lstm_step.hip).  (The per-sample magnitudes
+            # of h_{t-1} for the fp16x3 weight gradient are not published on this path: |h| < 1, the consumer measures.)
+            ops.lstm_step_fwd(hprev[:, t], pk.pkh["lstm.h/f"], pk.winv["lstm.h/f"], gx[:, t], call[:, t - 1], call[:, t],
+                              hprev[:, t + 1] if t + 1 < T else bott)
+            pk.uses_fp32.setdefault("lstm.h/f", False)
+            if be[1] is not None:
+                be[1].valid = False
+            continue
         if t > 0:
             # (slot t of every sample's row of the [B, T] table: first entry t, stride T)
             be_t = None if be[1] is None else ops.SampleExponents(be[1].t[t:], T)
@@ -689,9 +735,8 @@ def backward_decoder_lstm(p: Params, pk, g: Params, sv: Saved, dpred: Optional[T
     st = _BwdState()
     st.plan, st.ss, st.side, st.ds4, st.dcat, st.split = plan, ss, side, ds4, (dcat1, dcat2, dcat3), bucketed
     if bucketed:
-        ss.join()
         side.join()
-        plan.unpack("early")
+        ss.run_last(lambda: plan.unpack("early"))
     return st
 
 
@@ -711,9 +756,8 @@ def backward_encoder(p: Params, pk, g: Params, sv: Saved, st: "_BwdState", need_
     dp1 = _block_bwd(p, pk, g, gw, ss, "enc2.conv.", c2, ds2)
     ds1 = ops.maxpool2_bwd(c1.out, dp1, dcat1[:, b1:], t=T)
     dx = _block_bwd(p, pk, g, gw, ss, "enc1.", c1, ds1, need_dx=need_dx)
-    ss.join()
     st.side.join()
-    plan.unpack("late" if st.split else None)
+    ss.run_last(lambda: plan.unpack("late" if st.split else None))
     return dx.view(sv.x_shape) if dx is not None else None
 
 
@@ -786,6 +830,5 @@ def unet_backward(p: Params, pk, g: Params, sv: SavedUNet, dpred: Optional[Tenso
     dp1 = _block_bwd(p, pk, g, gw, ss, "enc2.conv.", c2, ds2)
     ds1 = ops.maxpool2_bwd(c1.out, dp1, dcat1[:, b1:], t=1)
     dx = _block_bwd(p, pk, g, gw, ss, "enc1.", c1, ds1, need_dx=need_dx)
-    ss.join()
-    plan.unpack()
+    ss.run_last(plan.unpack)
     return dx.view(sv.x_shape) if dx is not None else None

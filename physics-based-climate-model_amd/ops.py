@@ -545,7 +545,12 @@ def gates_bwd(dout, a2, s, z, pooled, gate, fmap, w1, w2, w7, dw1, dw2, dw7, def
 BLOCK_TAIL = os.environ.get("CM_BLOCK_TAIL", "1") != "0"      # sample-resident ConvBlock tail (csrc/block_tail.hip)
 
 
-def block_tail_supported(c, cr, h, w):
+BLOCK_TAIL_MIN_N = int(os.environ.get("CM_BLOCK_TAIL_MIN_N", "32"))    # fewer samples than this: keep the launch chain
+
+
+def block_tail_supported(c, cr, h, w, n=None):
+    if n is not None and n < BLOCK_TAIL_MIN_N:
+        return False
     return BLOCK_TAIL and bool(lib.cm_block_tail_supported(c, cr, h, w))
 
 
@@ -664,6 +669,26 @@ def lstm_gates_fwd(gates, c_prev, c_out, h_out, parts=None):
     check(lib.cm_lstm_gates_fwd(_p(gates), gates.stride(0), _p(c_prev), 0 if c_prev is None else c_prev.stride(0),
                                 _p(c_out), c_out.stride(0), _p(h_out), h_out.stride(0), b, ch, h * w, _stream()),
           "lstm_fwd")
+
+
+LSTM_STEP = os.environ.get("CM_LSTM_STEP", "1") != "0"        # fused ConvLSTM step (csrc/lstm_step.hip)
+
+
+def lstm_step_supported(b, ch, h, w):
+    return LSTM_STEP and bool(lib.cm_lstm_step_supported(b, ch, h, w))
+
+
+def lstm_step_fwd(hprev, wph, winv, gates, c_prev, c_out, h_out):
+    """One ConvLSTM step t >= 1 in one launch: gates (x-projection in, activations out) += conv3x3(hprev, W_h), then the
+    gate nonlinearities and the state update (cm_lstm_step_fwd)."""
+    b, ch4, h, w = gates.shape
+    ch = ch4 // 4
+    for t in (hprev, gates, c_prev, c_out, h_out):
+        if t.stride(3) != 1 or t.stride(2) != w or t.stride(1) != h * w:
+            raise RuntimeError("lstm_step_fwd needs dense HxW planes with channel stride H*W")
+    check(lib.cm_lstm_step_fwd(_p(hprev), hprev.stride(0), _p(wph), _p(winv), _p(gates), gates.stride(0), _p(c_prev),
+                               c_prev.stride(0), _p(c_out), c_out.stride(0), _p(h_out), h_out.stride(0), b, ch, h, w,
+                               _stream()), "lstm_step_fwd")
 
 
 def lstm_gates_bwd(gates, c_prev, c_cur, dh_a, dh_b, dc, first):

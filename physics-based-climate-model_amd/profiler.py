@@ -108,7 +108,8 @@ class KernelTimer:
         self.records = []
 
     def wrap(self, name, fn):
-        if name in ("cm_version", "cm_arch") or "pick_config" in name or "num_configs" in name or "packed_elems" in name or "scratch_elems" in name:
+        if name in ("cm_version", "cm_arch") or "pick_config" in name or "num_configs" in name or "packed_elems" in name or "scratch_elems" in name \
+                or "supported" in name or "packed_bytes" in name:
             return fn
 
         def timed(*a):

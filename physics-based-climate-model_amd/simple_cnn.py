@@ -198,7 +198,7 @@ class SimpleCNN(_HipModule):
             self.__dict__["_rng"][1] = 0          # the seed was drawn during the pass: keep it, rewind the counter
 
     # ------------------------------------------------------------------ engine
-    def _buffers(self) -> Dict[str, Tensor]:
+    def _bn_buffers(self) -> Dict[str, Tensor]:
         return dict(self.named_buffers())
 
     def _conv_units(self, p):
@@ -241,7 +241,7 @@ class SimpleCNN(_HipModule):
                                f"{p['initial.0.weight'].shape[1]}")
         x = x.contiguous()
         training = self.training
-        bufs = self._buffers()
+        bufs = self._bn_buffers()
         cs = self._conv_set(p, need_dx=True)
         sv = _Saved() if save else None
         y0 = cs.conv("initial.0", x, p["initial.0.weight"].shape[0], bias=p["initial.0.bias"])

@@ -85,9 +85,10 @@ class HotPathTrainer:
                 raise ValueError(f"micro_batches=2 needs an even batch, got {x.shape[0]}")
             if n == 2 and getattr(self.model, "batch_coupled", False):
                 raise ValueError("micro_batches=2 would change the model: its BatchNorm statistics run over the batch")
-            if n == 2 and self.use_graph and (engine.OVERLAP_WGRAD or engine.OVERLAP_LSTM) and not engine.PREFORK_OK:
-                raise ValueError("two micro-batches + side-stream overlap under graph capture needs the pre-forked "
-                                 "stream topology (engine.PREFORK_OK): a second-level fork crashes hipStreamEndCapture "
+            if n == 2 and self.use_graph and (engine.OVERLAP_LSTM or (engine.OVERLAP_WGRAD and not engine.PREFORK_OK)):
+                raise ValueError("two micro-batches under graph capture: the ConvLSTM side-stream overlap (its results are "
+                                 "consumed by the same half, which needs a fork + join between two forked streams) and the "
+                                 "un-preforked weight-gradient overlap crash hipStreamEndCapture "
                                  "(profiles/r03/capture_fork_probe.txt)")
             return n
         B = x.shape[0]
@@ -117,17 +118,21 @@ class HotPathTrainer:
         # a graph capture as FIRST-level forks of the origin stream and join it directly -- a stream that enters from the
         # second half's stream crashes hipStreamEndCapture (engine.PREFORK_OK, profiles/r03/capture_fork_probe.txt).
         children = []
-        if engine.PREFORK_OK and (engine.OVERLAP_WGRAD or engine.OVERLAP_LSTM):
+        if engine.PREFORK_OK and engine.OVERLAP_WGRAD:
             children = [engine._SideStream.child_of(self.device, st) for st in (main, self._side)]
             for c in children:
                 c.wait_stream(main)
-        self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):
-            fn(1)
-        fn(0)
-        main.wait_stream(self._side)
-        for c in children:
-            main.wait_stream(c)
+            engine._SideStream.origin = main
+        try:
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                fn(1)
+            fn(0)
+            main.wait_stream(self._side)
+            for c in children:
+                main.wait_stream(c)
+        finally:
+            engine._SideStream.origin = None
 
     def _fwd_bwd(self, x, y, phase=None, overlap=True):
         """phase None: the whole {zero, pack, forward, loss, backward}; "early": up to and including the decoder /
@@ -144,6 +149,7 @@ class HotPathTrainer:
                 self.grad[:bb].lerp_(self.grad2[:bb], 0.5)
             return
         self._parts = self._auto_micro(x)
+        engine.KEEP_ACTIVATION2 = bool(self.keep_saved)
         p = self.model._param_dict()
         gs = [self.model._views(self.grad), self.model._views(self.grad2)][:self._parts]
         nz = (nt + 1) if self._parts == 1 else self._gpitch + nt + 1

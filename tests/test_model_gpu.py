@@ -252,7 +252,7 @@ def test_baseline_configs_3_and_5_vs_fp64_oracle(amd, shape):
 
 
 # ----------------------------------------------------------------------------------------------- full-size, fused path
-def _check_checksums(g, loss, grads, pred=None):
+def _check_checksums(g, loss, grads, pred=None, grad_tol=TOL):
     """loss / prediction / per-tensor gradient norms against the reference's fp32 run, all at 1e-4.  (The 8 sampled
     elements per tensor stored in the fixture are not used: individual elements of the reference's OWN fp32 gradients
     are off by more than 1e-4 of the tensor's RMS wherever an argmax decision is ambiguous -- observed 2.7e-4 on
@@ -266,10 +266,10 @@ def _check_checksums(g, loss, grads, pred=None):
     if grads is None:
         return
     bad = []
-    for name, want, samp in zip(g["grad_names"].tolist(), g["grad_l2"].tolist(), g["grad_samples"]):
+    for name, want in zip(g["grad_names"].tolist(), g["grad_l2"].tolist()):
         got = grads[name]
         e_norm = abs(got.double().norm().item() - want) / max(want, 1e-30)
-        if e_norm > TOL:
+        if e_norm > grad_tol:
             bad.append((name, f"norm {e_norm:.2e}"))
     assert not bad, bad
 
@@ -539,9 +539,13 @@ def test_run_twice_determinism(amd):
                 assert rel_l2(gi[o:o + n], g0[o:o + n]) < 5e-5, k       # (observed <= 2.5e-6, SE weights up to 1.5e-5: cancelling sums, atomics order)
 
 
-def test_side_stream_overlap_eager_three_steps(amd, monkeypatch):
-    """CM_OVERLAP_WGRAD schedule (weight gradients on a second stream), EAGER, three steps at the benchmark size: the
-    configuration that produced non-finite gradients in round 1.  Finite, and equal to the serial schedule."""
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_side_stream_overlap_three_steps(amd, monkeypatch, use_graph):
+    """Weight gradients on side streams (engine.OVERLAP_WGRAD, off by default) beside two micro-batches, three steps at the
+    benchmark size: EAGER (the configuration that produced non-finite gradients in round 1) and GRAPH CAPTURED -- the
+    nested fork that crashed hipStreamEndCapture in round 2 and is recorded since round 3 with the side streams
+    pre-forked from the capture's origin and joined into it (engine._SideStream, profiles/r03/capture_fork_probe.txt).
+    Finite, and equal to the serial schedule."""
     from climate_amd import engine
     from climate_amd.trainer import HotPathTrainer
     in_ch, out_ch, base, T, B, H, W = 5, 2, 32, 6, 32, 48, 72
@@ -552,10 +556,11 @@ def test_side_stream_overlap_eager_three_steps(amd, monkeypatch):
     for overlap in (False, True):
         monkeypatch.setattr(engine, "OVERLAP_WGRAD", overlap)
         m = _make(amd, in_ch, out_ch, base, T)
-        tr = HotPathTrainer(m, lr=1e-3, use_graph=False, distributed=False)
+        tr = HotPathTrainer(m, lr=1e-3, use_graph=use_graph, distributed=False)
         losses, g1 = [], None
         for _ in range(3):
             losses.append(tr.step(x, y).item())
+            assert tr._parts == 2
             assert torch.isfinite(tr.grad).all(), (overlap, len(losses))
             if g1 is None:
                 g1 = tr.grad.clone()
@@ -568,6 +573,56 @@ def test_side_stream_overlap_eager_three_steps(amd, monkeypatch):
     lay = m._build_layout()
     for k, (o, n, _s) in lay.items():
         if o + n <= res[False][1].numel():
-            # (summation order of the float atomics differs between the schedules; the SE weight gradients are ~1e-9
-            #  sums of strongly cancelling terms: 1.5e-5 observed there, everything else <= 3e-6)
-            assert rel_l2(res[True][1][o:o + n], res[False][1][o:o + n]) < 5e-5, k
+            # (summation order of the float atomics differs between the schedules; the SE weight gradients are ~1e-8
+            #  sums of strongly cancelling terms over the two micro-batches: 7.5e-5 observed there, everything else <= 3e-6)
+            assert rel_l2(res[True][1][o:o + n], res[False][1][o:o + n]) < 2e-4, k
+
+
+@pytest.mark.parametrize("name", ["cfg3_b32_checksums.npz", "cfg5_b16_checksums.npz"])
+def test_configs_3_and_5_at_their_per_rank_batch_vs_reference_checksums(amd, name):
+    """BASELINE.json configs 3 and 5 at the PER-RANK batch they define (32 x 12 frames at base 64; 16 x 6 frames of
+    192x288 at base 64) through the graphed trainer -- the sample-group, grid-size and micro-batch choices of exactly
+    those shapes -- against checksums of the reference's own run (tests/golden/gen_golden_big.py): loss (1e-5),
+    prediction norm and samples (1e-5 / 1e-4), every per-tensor gradient norm.  The gradient norms are held to 1e-3 here,
+    not 1e-4: the reference's run is fp32, and at these sizes its own gradients sit up to 4.8e-4 from their float64
+    values wherever an amax / MaxPool decision is ambiguous (3e-4 observed on enc1.body.1.weight at
+    192x288) -- element-level parity at 1e-4 for these widths is the decision-aware float64 test above."""
+    from climate_amd.trainer import HotPathTrainer, InferenceRunner
+    g = load_golden(name)
+    in_ch, out_ch, base, T, B, H, W = (int(v) for v in g["cfg"])
+    m = _make(amd, in_ch, out_ch, base, T, salt=int(g["salt"]))
+    gen = torch.Generator("cpu").manual_seed(int(g["seed"]))
+    x = torch.randn(B, T, in_ch, H, W, generator=gen); y = torch.randn(B, out_ch, H, W, generator=gen)
+    xd, yd = x.cuda(), y.cuda()
+    pred = InferenceRunner(m, use_graph=False)(xd).clone()
+    tr = HotPathTrainer(m, lr=5e-4, use_graph=True, distributed=False)
+    loss = tr.step(xd, yd).item()
+    _check_checksums(g, loss, m._views(tr.grad), pred, grad_tol=1e-3)
+    l2 = tr.step(xd, yd).item()                       # graph replay
+    assert l2 < loss and torch.isfinite(tr.grad).all()
+
+
+def test_graph_replay_equals_eager_over_50_steps(amd):
+    """BASELINE config 2, two micro-batches on two streams: 50 graph-replayed steps against 50 eager steps of the same
+    schedule on a learnable synthetic task.  The two runs execute the same kernels in the same order; they differ only in
+    the order of float atomics (weight-gradient staging), so the loss trajectories must stay together (1e-3 relative after
+    50 Adam steps, 2e-5 over the first five) and the loss must fall."""
+    from climate_amd.config import synthetic_config
+    from climate_amd.model import get_model
+    from climate_amd.trainer import HotPathTrainer
+    cfg = synthetic_config(base_channels=32, seq_len=6)
+    gen = torch.Generator("cpu").manual_seed(7)
+    x = torch.randn(32, 6, 5, 48, 72, generator=gen).cuda()
+    y = (x[:, -1, :2] * 0.5 + x[:, 0, 1:3] * 0.25).contiguous()          # a learnable target
+    losses = {}
+    for graph in (True, False):
+        torch.manual_seed(cfg.seed)
+        m = get_model(cfg).cuda()
+        tr = HotPathTrainer(m, lr=1e-3, use_graph=graph, distributed=False, micro_batches=2)
+        losses[graph] = torch.stack([tr.step(x, y).clone() for _ in range(50)]).flatten().cpu()
+        assert tr._parts == 2
+    g, e = losses[True], losses[False]
+    assert torch.isfinite(g).all() and torch.isfinite(e).all()
+    assert ((g[:5] - e[:5]).abs() <= 2e-5 * e[:5].abs()).all(), (g[:5], e[:5])
+    assert ((g - e).abs() <= 1e-3 * e.abs()).all(), ((g - e).abs() / e.abs()).max()
+    assert g[-1] < 0.9 * g[0]

@@ -562,6 +562,38 @@ def test_lstm_gates(ops):
     assert rel_l2(gates, pd.grad) < TOL and rel_l2(dc, cpd.grad) < TOL
 
 
+@pytest.mark.parametrize("case", [(16, 128, 6, 9), (3, 64, 6, 9), (5, 256, 6, 9), (2, 128, 4, 6), (7, 128, 8, 8)])
+def test_lstm_step_fused(ops, case):
+    """cm_lstm_step_fwd (recurrent projection + gates + state update in one launch) vs ConvLSTMCell.forward in float64
+    (oracle.convlstm_cell, src/convlstm.py:11-19), on time slices of [B, T, ...] buffers as the engine passes them."""
+    b, ch, h, w = case
+    cx, T, t = 2 * ch, 3, 1
+    assert ops.lstm_step_supported(b, ch, h, w)
+    torch.manual_seed(4)
+    wl = torch.randn(4 * ch, cx + ch, 3, 3) * (1.0 / ((cx + ch) * 9) ** 0.5)
+    bl = torch.randn(4 * ch) * 0.1
+    x = torch.randn(b, cx, h, w)
+    hp = torch.tanh(torch.randn(b, T, ch, h, w))
+    cp = torch.randn(b, T, ch, h, w)
+    if b > 1:
+        hp[1] = 0.0                                   # an all-zero hidden state (left-padded window)
+    # x-projection (+ bias) the way the engine computes it, in float64 here
+    gx = torch.zeros(b, T, 4 * ch, h, w)
+    gx[:, t] = F.conv2d(x.double(), wl[:, :cx].double(), bl.double(), padding=1).float()
+    wph, winv = ops.pack_conv3x3_h3(dev(wl), c_off=cx, cin=ch)
+    gxd, hpd, cpd = dev(gx), dev(hp), dev(cp)
+    cout = torch.zeros(b, T, ch, h, w, device="cuda")
+    hout = torch.zeros(b, T, ch, h, w, device="cuda")
+    ops.lstm_step_fwd(hpd[:, t], wph, winv, gxd[:, t], cpd[:, t - 1], cout[:, t], hout[:, t])
+    h_ref, c_ref = oracle.convlstm_cell(x.double(), hp[:, t].double(), cp[:, t - 1].double(), wl.double(), bl.double())
+    assert rel_l2(hout[:, t], h_ref) < 2e-6 and rel_l2(cout[:, t], c_ref) < 2e-6
+    pre = F.conv2d(torch.cat([x, hp[:, t]], 1).double(), wl.double(), bl.double(), padding=1)
+    i_, f_, o_, g_ = pre.chunk(4, 1)
+    act = torch.cat([torch.sigmoid(i_), torch.sigmoid(f_), torch.sigmoid(o_), torch.tanh(g_)], 1)
+    assert rel_l2(gxd[:, t], act) < 2e-6
+    assert torch.all(gxd[:, 0] == 0) and torch.all(gxd[:, 2] == 0) and torch.all(cout[:, 0] == 0)   # neighbours untouched
+
+
 def test_conv_partial_slices_and_lstm_gates_parts(ops):
     """The ConvLSTM recurrence's launch form: cm_conv3x3_h3 with config bit 29 STORES its reduction shares as slices
     (no zero fill, no atomics); the gate kernels add them while reading (cm_lstm_gates_fwd_parts / _bwd_parts).
