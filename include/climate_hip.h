@@ -78,6 +78,17 @@ int cm_conv3x3_h3(const float* in0, long long st0, int c0, const float* in1, lon
                   const float* wscale_inv, const float* bias, const float* resid, long long st_resid, float* out,
                   long long st_out, unsigned* sample_be, long long be_stride, int n, int h, int w, int cout, int config,
                   cm_stream stream);
+/* GroupNorm(8) statistics in the convolution's epilogue (every ConvBlock conv feeds nn.GroupNorm(8, cout), src/unet.py:36-39):
+ * cm_conv3x3_h3_gn is cm_conv3x3_h3 (no reduction split, one sample per workgroup) that also writes, per (sample, group),
+ * gn_slots partial records {count, mean, sum of squares about that mean} of its OUTPUT -- a local two-pass over the
+ * accumulators of each workgroup's tile -- into gn_part [n][8][gn_slots][3]; cm_gn_silu_fwd_stats merges them, which
+ * removes GroupNorm's own statistics pass over the conv output.  cm_conv3x3_h3_gn_slots: records per (sample, group) this
+ * tile configuration writes, 0 = the configuration cannot (sample groups, reduction split, cout / 8 not a power of two >= 4). */
+int cm_conv3x3_h3_gn_slots(int config, int h, int w, int cout);
+int cm_conv3x3_h3_gn(const float* in0, long long st0, int c0, const float* in1, long long st1, int c1, const void* wps,
+                     const float* wscale_inv, const float* bias, const float* resid, long long st_resid, float* out,
+                     long long st_out, unsigned* sample_be, long long be_stride, float* gn_part, int gn_slots, int n, int h,
+                     int w, int cout, int config, cm_stream stream);
 
 /* Forward conv for VERY FEW input channels (cin * 9 <= 64; the first layer, src/unet.py:36 at
  * src/unet_convlstm_attention.py:35): the reduction index is the (input channel, tap) pair, fp32 MFMA, weights read
@@ -138,6 +149,11 @@ int cm_gn_silu_fwd(const float* x, const float* gamma, const float* beta, float*
 int cm_gn_silu_fwd_parts(const float* parts, long long zs, int nparts, float* xsum, const float* gamma,
                          const float* beta, float* y, float* stats, float* pooled, int n, int c, int hw, int groups,
                          float eps, cm_stream stream);
+/* cm_gn_silu_fwd whose statistics come from the producing convolution's epilogue (src/unet.py:36-39: conv -> GroupNorm):
+ * gpart [n][groups][gslots][3] = {count, mean, sum of squares about that mean} of the parts of each (sample, group), as
+ * cm_conv3x3_h3_gn writes them; they are merged (parallel-variance formula) and x is read ONCE. */
+int cm_gn_silu_fwd_stats(const float* x, const float* gpart, int gslots, const float* gamma, const float* beta, float* y,
+                         float* stats, float* pooled, int n, int c, int hw, int groups, float eps, cm_stream stream);
 /* dA = gradient wrt y (sample stride st_dA); dgamma/dbeta are ACCUMULATED (atomics). */
 int cm_gn_silu_bwd(const float* x, const float* gamma, const float* beta, const float* stats, const float* dA,
                    long long st_dA, float* dx, float* dgamma, float* dbeta, int n, int c, int hw, int groups,

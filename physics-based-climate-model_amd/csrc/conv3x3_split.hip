@@ -43,6 +43,8 @@ struct SplitArgs {
   long long be_stride;
   long long zstride;      // > 0 ("partial slices"): reduction share blockIdx.z STORES its partial sums into slice z of a
                           // [ksplit][N] stack (out + z * zstride) -- no zero fill, no atomics; the consumer adds the slices
+  float* gn_part;         // fp16x3, S == 1, no reduction split, optional: GroupNorm(8) partial statistics of the OUTPUT,
+  int gn_slots, gn_cpg;   // [N][8][gn_slots][3] = {count, mean, sum of squares about that mean} per (tile, co sub-block)
 };
 
 // Workgroups with one 32x32 tile per wave sit 2 registers above the 3-waves-per-SIMD allocation (170 of 168): ask for
@@ -51,8 +53,11 @@ struct SplitArgs {
 constexpr int split_min_waves(int waves, int npt, int wm) { return (npt * wm == 1 && waves == 4) ? 3 : 1; }
 
 // NP = 3: bf16x6 (three bf16 pieces, six products); NP = 2: fp16x3 (two fp16 pieces, three products; split_f16.h)
-template <int TH, int TW, int S, int WAVES, int NPT, int WM, bool DUAL, int NP>
+// GN: also write GroupNorm partial statistics of the output tile (fp16x3, one sample per workgroup; a separate
+// instantiation so that the plain kernels keep their register allocation)
+template <int TH, int TW, int S, int WAVES, int NPT, int WM, bool DUAL, int NP, bool GN = false>
 __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void conv3x3_split_kernel(SplitArgs a) {
+  static_assert(!GN || (NP == 2 && S == 1), "epilogue statistics: fp16x3, one sample per workgroup");
   constexpr int THREADS = WAVES * 64;
   constexpr int PITCH = TW + 2;
   constexpr int SS = (TH + 2) * PITCH;
@@ -435,6 +440,87 @@ __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void c
         for (int r = 0; r < 16; ++r) acc[m][p][r] += rv[r];
       }
   }
+  if constexpr (GN) {
+    // GroupNorm statistics of this workgroup's output tile, from the accumulators (reference: nn.GroupNorm(8, c) right
+    // after the conv, src/unet.py:36-39): per group a LOCAL two-pass -- mean of the tile's part of the group, then the sum
+    // of squares about that mean -- stored as {count, mean, M2}; the consumer (cm_gn_silu_fwd_stats) merges the parts of a
+    // (sample, group) with the parallel-variance formula, so no pivot has to be agreed on between workgroups.
+    // A lane's registers r = 4k + j (j = 0..3) are 4 consecutive channels co0 + 32 m + 8 k + 4 half + j: for groups of
+    // >= 4 channels they belong to ONE group, so a lane keeps one partial per (m, k) and the 32 lanes of a half are added
+    // by DPP; the few per-wave results go through LDS atomics.
+    {
+      // per-wave slots, written by lane 0 only and added in wave order: deterministic (the amax / MaxPool decisions
+      // downstream depend on the statistics bit for bit, and two runs must take the same ones)
+      __shared__ float gw[2][WAVES][16], gcw[WAVES][16], gsum[2][16], gcnt[16];
+      const int cpg = a.gn_cpg;
+      const int ngl = max(1, BCO / cpg);               // groups (or one part of a group) in this co block
+      if (lane < 16) { gw[0][wave][lane] = 0.f; gw[1][wave][lane] = 0.f; gcw[wave][lane] = 0.f; }
+      auto group_of = [&](int m, int k, int hf) { return min((m * 32 + 8 * k + 4 * hf) / cpg, ngl - 1); };
+      auto lane_reduce = [&](float v, float& lo, float& hi) {
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, true));
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, true));
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, true));
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, true));
+        lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+        hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+      };
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float mean = pass == 0 ? 0.f : gsum[0][group_of(m, k, half)];
+            float v = 0.f, c = 0.f;
+#pragma unroll
+            for (int p = 0; p < NPT; ++p)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const bool ok = pvalid[p] && (co0 + m * 32 + 8 * k + 4 * half + j) < a.Cout;
+                const float d = acc[m][p][4 * k + j] - mean;
+                v += ok ? (pass == 0 ? d : d * d) : 0.f;
+                c += ok ? 1.f : 0.f;
+              }
+            float lo, hi, clo = 0.f, chi = 0.f;
+            lane_reduce(v, lo, hi);
+            if (pass == 0) lane_reduce(c, clo, chi);
+            if (lane == 0) {                           // (one lane, program order: no atomics needed)
+              gw[pass][wave][group_of(m, k, 0)] += lo;
+              gw[pass][wave][group_of(m, k, 1)] += hi;
+              if (pass == 0) {
+                gcw[wave][group_of(m, k, 0)] += clo;
+                gcw[wave][group_of(m, k, 1)] += chi;
+              }
+            }
+          }
+        __syncthreads();
+        if (tid < ngl) {
+          float t = 0.f, cn = 0.f;
+#pragma unroll
+          for (int w2 = 0; w2 < WAVES; ++w2) { t += gw[pass][w2][tid]; cn += gcw[w2][tid]; }
+          if (pass == 0) {
+            gcnt[tid] = cn;
+            gsum[0][tid] = cn > 0.f ? t / cn : 0.f;    // local mean
+          } else {
+            gsum[1][tid] = t;
+          }
+        }
+        __syncthreads();
+      }
+      if (tid < ngl && n0 < a.N) {
+        const int sb = max(1, cpg / BCO);                           // co blocks per group (groups wider than the block)
+        const int g = (co0 + tid * cpg) / cpg;
+        const int slot = (ty * a.tiles_x + tx) * sb + (sb > 1 ? (int)(blockIdx.y % sb) : 0);
+        if (g < 8) {
+          float* dst = a.gn_part + (((long long)n0 * 8 + g) * a.gn_slots + slot) * 3;
+          dst[0] = gcnt[tid];
+          dst[1] = gsum[0][tid];
+          dst[2] = gsum[1][tid];
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int m = 0; m < WM; ++m)
 #pragma unroll
@@ -601,7 +687,17 @@ int launch_s(const SplitArgs& a0, hipStream_t st) {
     const long long zb = ((long long)a.N * per + 255) / 256;
     zero_out_split_kernel<<<(int)(zb > 2048 ? 2048 : zb), 256, 0, st>>>(a.out, a.sto, a.N, per);
   }
+  if (a.gn_part && (c.s != 1 || a.ksplit > 1 || a.zstride > 0 ||
+                    a.gn_slots != a.tiles_x * a.tiles_y * (a.gn_cpg > 32 * c.wm ? a.gn_cpg / (32 * c.wm) : 1)))
+    return -22;          // (the caller sized the partial-statistics buffer with cm_conv3x3_h3_gn_slots for this config)
   dim3 grid(a.tiles_x * a.tiles_y * cdiv(a.N, c.s), cdiv(a.Cout, 32 * c.wm), a.ksplit);
+  if constexpr (NP == 2 && c.s == 1) {
+    if (a.gn_part) {
+      conv3x3_split_kernel<c.th, c.tw, c.s, c.waves, c.npt, c.wm, DUAL, NP, true><<<grid, c.waves * 64, 0, st>>>(a);
+      CM_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   conv3x3_split_kernel<c.th, c.tw, c.s, c.waves, c.npt, c.wm, DUAL, NP><<<grid, c.waves * 64, 0, st>>>(a);
   CM_CHECK_LAUNCH();
   return 0;
@@ -707,6 +803,7 @@ int cm_conv3x3_split(const float* in0, long long st0, int c0, const float* in1, 
   a.tiles_x = a.tiles_y = 0;
   a.winv = nullptr;
   a.be_out = nullptr; a.be_stride = 0; a.zstride = 0;
+  a.gn_part = nullptr; a.gn_slots = 0; a.gn_cpg = 0;
   if (!offsets_fit_32bit(a)) return -22;
   return c1 > 0 ? dispatch_s<true, 3>(config, a, (hipStream_t)stream) : dispatch_s<false, 3>(config, a, (hipStream_t)stream);
 }
@@ -744,6 +841,53 @@ int cm_conv3x3_h3(const float* in0, long long st0, int c0, const float* in1, lon
   a.tiles_x = a.tiles_y = 0;
   a.winv = wscale_inv;
   a.be_out = sample_be; a.be_stride = be_stride;
+  a.gn_part = nullptr; a.gn_slots = 0; a.gn_cpg = 0;
+  if (!offsets_fit_32bit(a)) return -22;
+  return c1 > 0 ? dispatch_s<true, 2>(config, a, (hipStream_t)stream) : dispatch_s<false, 2>(config, a, (hipStream_t)stream);
+}
+
+/* GroupNorm(8) partial statistics from the conv epilogue (src/unet.py:36-39: every ConvBlock conv is followed by
+ * nn.GroupNorm(8, cout)): number of {count, mean, M2} records per (sample, group) that cm_conv3x3_h3_gn writes with this
+ * configuration, or 0 when the configuration cannot produce them (sample groups, a reduction split, partial slices, cout
+ * not 8 groups of a power-of-two >= 4 channels). */
+int cm_conv3x3_h3_gn_slots(int config, int h, int w, int cout) {
+  if (config < 0 || h <= 0 || w <= 0 || cout <= 0 || cout % 8) return 0;
+  if ((config >> 29) & 1) return 0;
+  config &= ~(1 << 30);
+  if ((config >> 8) > 1) return 0;
+  const int ci = config & 0xff;
+  if (ci >= kNumS) return 0;
+  const SCfg c = kS[ci];
+  const int cpg = cout / 8;
+  if (c.s != 1 || cpg < 4 || (cpg & (cpg - 1))) return 0;
+  const int sb = cpg > 32 * c.wm ? cpg / (32 * c.wm) : 1;
+  return cdiv(w, c.tw) * cdiv(h, c.th) * sb;
+}
+
+/* cm_conv3x3_h3 that also writes those partial statistics of its output: gn_part [n][8][gn_slots][3] floats,
+ * gn_slots = cm_conv3x3_h3_gn_slots(config, h, w, cout) > 0.  Consumer: cm_gn_silu_fwd_stats. */
+int cm_conv3x3_h3_gn(const float* in0, long long st0, int c0, const float* in1, long long st1, int c1, const void* wps,
+                     const float* wscale_inv, const float* bias, const float* resid, long long st_resid, float* out,
+                     long long st_out, unsigned* sample_be, long long be_stride, float* gn_part, int gn_slots, int n, int h,
+                     int w, int cout, int config, cm_stream stream) {
+  if (n <= 0 || h <= 0 || w <= 0 || cout <= 0 || c0 <= 0 || c1 < 0 || config < 0 || !wscale_inv) return -22;
+  if (c1 > 0 && (c0 % SKC) != 0) return -22;
+  if (resid && st_resid != st_out) return -22;
+  if (!gn_part || gn_slots <= 0 || gn_slots != cm_conv3x3_h3_gn_slots(config, h, w, cout)) return -22;
+  SplitArgs a;
+  a.in0 = in0; a.in1 = in1; a.st0 = st0; a.st1 = st1; a.C0 = c0; a.C1 = c1;
+  a.wps = (const u32x4*)wps; a.bias = bias; a.resid = resid; a.out = out; a.sto = st_out;
+  a.N = n; a.H = h; a.W = w; a.Cout = cout;
+  a.CoutP = ((cout + 31) / 32) * 32;
+  a.nsteps = (c0 + c1 + SKC - 1) / SKC;
+  a.prezeroed = 0;
+  a.ksplit = 1;
+  config &= 0xff;
+  a.zstride = 0;
+  a.tiles_x = a.tiles_y = 0;
+  a.winv = wscale_inv;
+  a.be_out = sample_be; a.be_stride = be_stride;
+  a.gn_part = gn_part; a.gn_slots = gn_slots; a.gn_cpg = cout / 8;
   if (!offsets_fit_32bit(a)) return -22;
   return c1 > 0 ? dispatch_s<true, 2>(config, a, (hipStream_t)stream) : dispatch_s<false, 2>(config, a, (hipStream_t)stream);
 }

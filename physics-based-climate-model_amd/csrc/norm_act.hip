@@ -50,14 +50,19 @@ __device__ __forceinline__ float gn_silu_value(float v, float ga, float be) {
 // PARTS: x arrives as nparts partial sums (slices zs apart: what a "partial slices" cm_conv3x3_h3 launch stores); the
 // statistics pass adds them in slice order, WRITES the sum to xsum (the conv output the backward needs) and the apply pass
 // re-reads it from there like the plain form re-reads x.
-template <bool VEC, int LPC, bool PARTS>   // LPC lanes cooperate on one channel (64: a wave, 16: four channels per wave)
+// GPART: the statistics come as partial {count, mean, M2} records written by the producing convolution's epilogue
+// (cm_conv3x3_h3_gn: gpart [N][G][gslots][3]); they are merged with the parallel-variance formula and the statistics pass
+// over x is skipped -- x is then read once.
+template <bool VEC, int LPC, bool PARTS, bool GPART = false>   // LPC lanes cooperate on one channel (64: a wave, 16: four channels per wave)
 __global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_kernel(const float* __restrict__ x,
                                                                    const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta,
                                                                    float* __restrict__ y, float* __restrict__ stats,
                                                                    float* __restrict__ pooled, int C, int HW,
                                                                    int G, float eps, const float* __restrict__ parts,
-                                                                   long long zs, int nparts, float* xsum) {
+                                                                   long long zs, int nparts, float* xsum,
+                                                                   const float* __restrict__ gpart = nullptr,
+                                                                   int gslots = 0) {
   __shared__ float red[32];
   const int n = blockIdx.x / G, g = blockIdx.x % G;
   const int cpg = C / G;
@@ -94,6 +99,23 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_kernel(const float* __
   // over the whole group, i.e. within ~sigma/16 of the group mean, so E[d^2] - E[d]^2 does not cancel (a single
   // element as pivot -- e.g. the zero-padded corner pixel -- can sit many sigma out, which cost 10x in the error of
   // rstd: tools/noise_probe.py).  The apply pass then re-reads the group from L2.
+  float mean, rstd;
+  if constexpr (GPART) {
+    // merge the producer's partial statistics: n = sum n_i, mean = sum n_i mean_i / n, M2 = sum M2_i + sum n_i (mean_i - mean)^2
+    const float* gp = gpart + (long long)blockIdx.x * gslots * 3;
+    float cn = 0.f, cm = 0.f;
+    for (int i = tid; i < gslots; i += GN_THREADS) { cn += gp[3 * i]; cm += gp[3 * i] * gp[3 * i + 1]; }
+    cn = block_sum(cn, red);
+    cm = block_sum(cm, red);
+    mean = cm / cn;
+    float m2 = 0.f;
+    for (int i = tid; i < gslots; i += GN_THREADS) {
+      const float d = gp[3 * i + 1] - mean;
+      m2 += gp[3 * i + 2] + gp[3 * i] * d * d;
+    }
+    m2 = block_sum(m2, red);
+    rstd = rsqrtf(fmaxf(m2 / cn, 0.f) + eps);
+  } else {
   const float pivot = block_sum(xg[(long long)tid * L / GN_THREADS], red) * (1.f / GN_THREADS);
   float s1 = 0.f, s2 = 0.f;
   if (VEC) {
@@ -113,9 +135,10 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_kernel(const float* __
   }
   s1 = block_sum(s1, red) / (float)L;
   s2 = block_sum(s2, red) / (float)L;
-  const float mean = pivot + s1;
+  mean = pivot + s1;
   const float var = fmaxf(s2 - s1 * s1, 0.f);
-  const float rstd = rsqrtf(var + eps);
+  rstd = rsqrtf(var + eps);
+  }
   if (tid == 0) {
     stats[2 * blockIdx.x] = mean;
     stats[2 * blockIdx.x + 1] = rstd;
@@ -543,6 +566,20 @@ int cm_gn_silu_fwd(const float* x, const float* gamma, const float* beta, float*
     return 0;
   }
 #define GN_FWD(V, L) gn_silu_fwd_kernel<V, L, false><<<n * groups, GN_THREADS, 0, st>>>(x, gamma, beta, y, stats, pooled, c, hw, groups, eps, nullptr, 0, 0, nullptr)
+  if (vec) { if (narrow) GN_FWD(true, 16); else GN_FWD(true, 64); }
+  else     { if (narrow) GN_FWD(false, 16); else GN_FWD(false, 64); }
+#undef GN_FWD
+  CM_CHECK_LAUNCH();
+  return 0;
+}
+
+int cm_gn_silu_fwd_stats(const float* x, const float* gpart, int gslots, const float* gamma, const float* beta, float* y,
+                         float* stats, float* pooled, int n, int c, int hw, int groups, float eps, cm_stream stream) {
+  if (n <= 0 || c <= 0 || hw <= 0 || groups <= 0 || c % groups || !gpart || gslots <= 0) return -22;
+  const bool vec = (hw % 4) == 0;
+  const bool narrow = (vec ? hw / 4 : hw) <= 64 && (c / groups) >= 8;
+  hipStream_t st = (hipStream_t)stream;
+#define GN_FWD(V, L) gn_silu_fwd_kernel<V, L, false, true><<<n * groups, GN_THREADS, 0, st>>>(x, gamma, beta, y, stats, pooled, c, hw, groups, eps, nullptr, 0, 0, nullptr, gpart, gslots)
   if (vec) { if (narrow) GN_FWD(true, 16); else GN_FWD(true, 64); }
   else     { if (narrow) GN_FWD(false, 16); else GN_FWD(false, 64); }
 #undef GN_FWD

@@ -89,6 +89,7 @@ class _Packs:
         self.packed_fp32 = packed_fp32            # keys whose fp32-MFMA operand was re-packed this step (None = all)
 
     def conv(self, key, x0, cout, **kw):
+        """kw: x1, bias, resid, out, out_zeroed, be_out, gn_out (ops.conv3x3)."""
         wp = self.pk[key] if (self.packed_fp32 is None or key in self.packed_fp32) else None
         out = ops.conv3x3(x0, wp, cout, wps=self.pks.get(key), w_raw=self.raw.get(key), wph=self.pkh.get(key),
                           winv=self.winv.get(key), **kw)
@@ -328,8 +329,9 @@ def _block_fwd(p: Params, pk, prefix: str, x0: Tensor, x1: Optional[Tensor], sav
     if r1 is not None:
         a1, st1, _, y1 = ops.gn_silu_fwd(None, p[prefix + "body.1.weight"], p[prefix + "body.1.bias"], parts=r1)
     else:
-        y1 = pk.conv(prefix + "body.0.weight/f", x0, co, x1=x1, be_out=be[0])
-        a1, st1, _ = ops.gn_silu_fwd(y1, p[prefix + "body.1.weight"], p[prefix + "body.1.bias"])
+        gn1 = ops.GnPartials()         # GroupNorm statistics from the conv's epilogue where its tile configuration allows
+        y1 = pk.conv(prefix + "body.0.weight/f", x0, co, x1=x1, be_out=be[0], gn_out=gn1)
+        a1, st1, _ = ops.gn_silu_fwd(y1, p[prefix + "body.1.weight"], p[prefix + "body.1.bias"], gn=gn1)
     r2 = pk.conv_parts(prefix + "body.3.weight/f", a1, co, be_out=be[1]) if _small_launch(a1, co, co) else None
     g2, b2 = p[prefix + "body.4.weight"], p[prefix + "body.4.bias"]
     w1, w2, w7 = p[prefix + "se.fc.0.weight"], p[prefix + "se.fc.2.weight"], p[prefix + "spat.conv.weight"]
@@ -342,8 +344,9 @@ def _block_fwd(p: Params, pk, prefix: str, x0: Tensor, x1: Optional[Tensor], sav
         if r2 is not None:
             a2, st2, pooled, y2 = ops.gn_silu_fwd(None, g2, b2, want_pooled=True, parts=r2)
         else:
-            y2 = pk.conv(prefix + "body.3.weight/f", a1, co, be_out=be[1])
-            a2, st2, pooled = ops.gn_silu_fwd(y2, g2, b2, want_pooled=True)
+            gn2 = ops.GnPartials()
+            y2 = pk.conv(prefix + "body.3.weight/f", a1, co, be_out=be[1], gn_out=gn2)
+            a2, st2, pooled = ops.gn_silu_fwd(y2, g2, b2, want_pooled=True, gn=gn2)
         res = ops.se_spatial_gate_fwd(a2, pooled, w1, w2, w7, pool_out=pool)
         out, z, s, fmap, gate = res[:5]
         mp = res[5] if pool else None

@@ -139,8 +139,24 @@ class SampleExponents:
         return se
 
 
+# GroupNorm statistics from the conv epilogue (cm_conv3x3_h3_gn -> cm_gn_silu_fwd_stats): built and parity-tested, OFF by
+# default -- measured 0.8 % SLOWER at config 2 (tools/ab_bench.py, same box: 8376 vs 8447 samples/s): the two extra
+# barriers and reductions sit on every conv workgroup's critical path, while the pass they save re-reads the conv output
+# from L2 in a launch that is short anyway.  CM_GN_EPILOGUE=1 switches it on.
+GN_EPILOGUE = os.environ.get("CM_GN_EPILOGUE", "0") != "0"
+
+
+class GnPartials:
+    """GroupNorm(8) partial statistics of a conv output, written by the conv's own epilogue (cm_conv3x3_h3_gn) when the
+    tile configuration the call runs with can produce them: ``t`` [n, 8, slots, 3] or None.  Handed to gn_silu_fwd."""
+    __slots__ = ("t", "slots")
+
+    def __init__(self):
+        self.t, self.slots = None, 0
+
+
 def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1, wps=None, w_raw=None,
-            out_zeroed=False, wph=None, winv=None, be_out=None):
+            out_zeroed=False, wph=None, winv=None, be_out=None, gn_out=None):
     """out = conv3x3(cat(x0, x1), wp) + bias + resid.  x0/x1: [N,C,H,W] (sample stride may exceed C*H*W).
 
     ``wp`` is the fp32-MFMA operand (cm_pack_conv3x3); ``wps`` (optional) the bf16x6 operand of the same weight;
@@ -223,6 +239,17 @@ def conv3x3(x0, wp, cout, x1=None, bias=None, resid=None, out=None, config=-1, w
         return out
     if config >= H3_BASE:
         cfg = config - H3_BASE
+        slots = lib.cm_conv3x3_h3_gn_slots(cfg, h, w, cout) if (gn_out is not None and GN_EPILOGUE) else 0
+        if slots > 0:
+            gn_out.t = torch.empty(n, GN_GROUPS, slots, 3, device=x0.device, dtype=torch.float32)
+            gn_out.slots = slots
+            check(lib.cm_conv3x3_h3_gn(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(wph), _p(winv), _p(bias), _p(resid),
+                                       0 if resid is None else resid.stride(0), _p(out), out.stride(0),
+                                       None if be_out is None else _p_any(be_out.t), 0 if be_out is None else be_out.stride,
+                                       _p(gn_out.t), slots, n, h, w, cout, cfg, _stream()), "conv3x3_h3_gn")
+            if be_out is not None:
+                be_out.valid = True
+            return out
         if out_zeroed and (cfg >> 8) > 1:
             cfg |= 1 << 30
         check(lib.cm_conv3x3_h3(_p(x0), x0.stride(0), c0, _p(x1), st1, c1, _p(wph), _p(winv), _p(bias), _p(resid),
@@ -414,9 +441,18 @@ def wgrad3x3_unpack(g, scale=1.0):
 
 
 # ----------------------------------------------------------------------------------------------------- GN + SiLU
-def gn_silu_fwd(x, gamma, beta, want_pooled=False, parts=None):
+def gn_silu_fwd(x, gamma, beta, want_pooled=False, parts=None, gn=None):
     """parts = (stack [>= k, N, C, H, W], k) from conv3x3_parts instead of x: the launch adds the slices and returns the
-    summed conv output as a fourth value (x is ignored)."""
+    summed conv output as a fourth value (x is ignored).  gn (GnPartials with .t set): the statistics the producing conv's
+    epilogue wrote -- the launch merges them instead of making its own statistics pass over x."""
+    if gn is not None and gn.t is not None and parts is None:
+        n, c, h, w = x.shape
+        y = torch.empty_like(_contig(x))
+        stats = torch.empty(n * GN_GROUPS * 2, device=x.device, dtype=torch.float32)
+        pooled = torch.empty(n, c, device=x.device, dtype=torch.float32) if want_pooled else None
+        check(lib.cm_gn_silu_fwd_stats(_p(x), _p(gn.t), gn.slots, _p(gamma), _p(beta), _p(y), _p(stats), _p(pooled), n, c,
+                                       h * w, GN_GROUPS, GN_EPS, _stream()), "gn_silu_fwd_stats")
+        return y, stats, pooled
     if parts is not None:
         pt, k = parts
         _, n, c, h, w = pt.shape

@@ -342,6 +342,52 @@ def test_fused_se_stats_equals_separate_launches(ops, shape):
     assert rel_l2(out1, ref) < TOL
 
 
+@pytest.mark.parametrize("case", [(6, 32, 0, 32, 48, 72), (5, 32, 0, 64, 24, 36), (4, 64, 64, 128, 12, 18), (3, 16, 0, 256, 6, 9),
+                                  (2, 32, 0, 512, 6, 9), (3, 32, 32, 32, 20, 28)])
+def test_groupnorm_statistics_from_the_conv_epilogue(ops, case, monkeypatch):
+    """cm_conv3x3_h3_gn: every tile configuration that can write GroupNorm partial statistics ({count, mean, M2} per
+    workgroup tile, local two-pass over the accumulators) must produce, through cm_gn_silu_fwd_stats, the same mean / rstd
+    and the same activation as GroupNorm's own statistics pass (and as torch in float64); an offset input (mean >> sigma)
+    checks that nothing cancels."""
+    n, c0, c1, cout, h, w = case
+    monkeypatch.setattr(ops, "GN_EPILOGUE", True)       # (off by default: measured slower, see ops.GN_EPILOGUE)
+    torch.manual_seed(8)
+    x0 = torch.randn(n, c0, h, w, device="cuda") + 3.0
+    x1 = torch.randn(n, c1, h, w, device="cuda") if c1 else None
+    wt = torch.randn(cout, c0 + c1, 3, 3, device="cuda") * 0.05
+    bias = torch.randn(cout, device="cuda") * 2.0
+    gamma = torch.randn(cout, device="cuda") * 0.3 + 1.0
+    beta = torch.randn(cout, device="cuda") * 0.2
+    wph, winv = ops.pack_conv3x3_h3(wt)
+    from climate_amd._lib import lib
+    ncfg = lib.cm_conv3x3_split_num_configs()
+    seen = 0
+    for cfg in range(ncfg):
+        slots = lib.cm_conv3x3_h3_gn_slots(cfg, h, w, cout)
+        if slots == 0:
+            continue
+        gn = ops.GnPartials()
+        try:
+            y = ops.conv3x3(x0, None, cout, x1=x1, bias=bias, wph=wph, winv=winv, config=ops.H3_BASE + cfg, gn_out=gn)
+        except RuntimeError:
+            continue                                  # configuration not applicable to this call
+        assert gn.t is not None and gn.slots == slots
+        gn_b = ops.GnPartials()
+        ops.conv3x3(x0, None, cout, x1=x1, bias=bias, wph=wph, winv=winv, config=ops.H3_BASE + cfg, gn_out=gn_b)
+        assert torch.equal(gn.t, gn_b.t), cfg             # deterministic: fixed reduction order, no atomics
+        seen += 1
+        a_ref, st_ref, p_ref = ops.gn_silu_fwd(y, gamma, beta, want_pooled=True)
+        a, st, p = ops.gn_silu_fwd(y, gamma, beta, want_pooled=True, gn=gn)
+        assert rel_l2(st, st_ref) < 2e-6, cfg
+        assert rel_l2(a, a_ref) < 2e-6 and rel_l2(p, p_ref) < 2e-6, cfg
+        assert int(gn.t[..., 0].sum().item()) == n * cout * h * w, cfg          # every element counted exactly once
+        ref = F.silu(F.group_norm(y.double().cpu(), 8, gamma.double().cpu(), beta.double().cpu(), 1e-5))
+        assert rel_l2(a, ref) < 2e-6, cfg
+    assert seen >= 4
+    # configurations that cannot: sample groups and reduction splits
+    assert lib.cm_conv3x3_h3_gn_slots(5, h, w, cout) == 0 and lib.cm_conv3x3_h3_gn_slots(0 + (2 << 8), h, w, cout) == 0
+
+
 TAIL_SHAPES = [(5, 64, 24, 36), (7, 128, 12, 18), (6, 256, 6, 9), (3, 16, 8, 12), (4, 8, 6, 4), (2, 256, 12, 18),
                (3, 512, 6, 9), (96, 64, 24, 36), (2, 24, 4, 6)]
 

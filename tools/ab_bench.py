@@ -3,7 +3,7 @@
 
     python tools/ab_bench.py [--rounds 3] [--steps 30] [--out gpurun_out/ab.txt] [variant ...]
 
-Variants: base | tail_off | tail_min32 | tail_min17 | lstm_step_off | overlap_wgrad | micro1
+Variants: base | tail_off | tail_min<N> | lstm_step_off | overlap_wgrad | micro1 | gn_epi_off
 """
 import argparse
 import os
@@ -19,12 +19,14 @@ from climate_amd.config import synthetic_config  # noqa: E402
 from climate_amd.model import get_model  # noqa: E402
 from climate_amd.trainer import HotPathTrainer  # noqa: E402
 
-DEFAULTS = dict(tail=ops.BLOCK_TAIL, tail_min=ops.BLOCK_TAIL_MIN_N, lstm=ops.LSTM_STEP, ow=engine.OVERLAP_WGRAD)
+DEFAULTS = dict(tail=ops.BLOCK_TAIL, tail_min=ops.BLOCK_TAIL_MIN_N, lstm=ops.LSTM_STEP, ow=engine.OVERLAP_WGRAD,
+                gn=ops.GN_EPILOGUE)
 
 
 def apply(v):
     ops.BLOCK_TAIL, ops.BLOCK_TAIL_MIN_N, ops.LSTM_STEP, engine.OVERLAP_WGRAD = (DEFAULTS["tail"], DEFAULTS["tail_min"],
                                                                                  DEFAULTS["lstm"], DEFAULTS["ow"])
+    ops.GN_EPILOGUE = DEFAULTS["gn"]
     micro = None
     if v == "tail_off":
         ops.BLOCK_TAIL = False
@@ -36,6 +38,8 @@ def apply(v):
         engine.OVERLAP_WGRAD = True
     elif v == "micro1":
         micro = 1
+    elif v == "gn_epi_off":
+        ops.GN_EPILOGUE = False
     elif v != "base":
         raise SystemExit(f"unknown variant {v}")
     return micro

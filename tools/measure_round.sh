@@ -6,7 +6,7 @@
 #   3. rocprofv3 --kernel-trace --stats of the same bench command (kernel_stats CSV)
 #   4. two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counters only, no trace domains) -> pmc_traffic.json
 set -o pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
