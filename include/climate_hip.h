@@ -300,6 +300,16 @@ int cm_lstm_step_fwd(const float* hprev, long long sh, const void* wph, const fl
                      long long sg, const float* c_prev, long long scp, float* c_out, long long sco, float* h_out,
                      long long sho, int b, int ch, int h, int w, cm_stream stream);
 
+/* One BPTT step t < T-1 as ONE launch: dh_t = dh_ext + conv3x3(dA_{t+1}, W_h^T flipped) (fp16x3), then the gate backward
+ * of step t (autograd of src/convlstm.py:13-19): gates [b,4ch,hw] holds the step's activations on entry and
+ * d(pre-activations) on exit; dA_next = the already-overwritten gates of step t+1; dc [b,ch,hw] carries dL/dc; dh_ext
+ * nullable.  wpd / wscale_inv: the data-gradient operand of the weight's h-columns (cm_pack_conv3x3_h3_batch, dgrad = 1).
+ * Replaces cm_conv3x3_h3 (partial slices) + cm_lstm_gates_bwd_parts.  Supported: ch in {64, 128}, h*w <= 64. */
+int cm_lstm_step_bwd_supported(int b, int ch, int h, int w);
+int cm_lstm_step_bwd(const float* dA_next, long long sdn, const void* wpd, const float* wscale_inv, float* gates,
+                     long long sg, const float* c_prev, long long scp, const float* c_cur, long long scc,
+                     const float* dh_ext, long long sde, float* dc, int b, int ch, int h, int w, cm_stream stream);
+
 /* The same two stages fed by a "partial slices" recurrent projection (cm_conv3x3_h3 config bit 29: the reduction shares
  * of the h-projection / its data gradient are STORED as nparts slices instead of being added with atomics -- the
  * recurrence is a chain of small launches whose cost is latency, and the atomics were half of it):

@@ -11,10 +11,18 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Sum over the 64 lanes, returned wave-uniform.  Six DPP adds (row shifts 1/2/4/8 inside the 16-lane rows, then
+// row_bcast:15 / row_bcast:31 across rows: lane 63 ends with the total) + one readlane, instead of six ds_bpermute round
+// trips through the LDS crossbar (__shfl_xor) -- the reductions of the small per-sample kernels are latency chains of
+// exactly these.  Fixed summation order.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));    // row_shr:1
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, true));    // row_shr:2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, true));    // row_shr:4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, true));    // row_shr:8
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, true));    // row_bcast:15
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, true));    // row_bcast:31
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

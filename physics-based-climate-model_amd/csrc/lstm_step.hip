@@ -159,6 +159,158 @@ __global__ __launch_bounds__(NW * 64, 1) void lstm_step_fwd_kernel(LstmStep a) {
   }
 }
 
+// ================================================================================================ backward step
+// BPTT step t < T-1 as one launch: dh_t = dh_ext + conv3x3(dA_{t+1}, W_h^T flipped) (the recurrent data gradient, fp16x3
+// on the matrix cores), then the gate backward of step t (src/convlstm.py:14-19 under autograd):
+//   tc = tanh(c_t); dc_t = dc_carry + dh_t o (1 - tc^2); dA_t = [dc_t g i(1-i), dc_t c_{t-1} f(1-f), dh_t tc o(1-o),
+//   dc_t i (1-g^2)]; dc_carry = dc_t f.
+// Replaces cm_conv3x3_h3 (partial slices) + cm_lstm_gates_bwd_parts.  Workgroup = (32 hidden channels, one sample), 8
+// waves; the reduction over the 4 Ch gate channels x 9 taps is split over the waves, each streaming ITS weight fragments
+// from the packed operand into registers in PHASES of two 16-channel stages (144 VGPRs); dA_{t+1} of the sample is staged
+// once, split into two fp16 pieces with a per-sample power-of-two scale (its magnitudes are unbounded), WITHOUT a halo: a
+// tap outside the image reads a zero record.
+struct LstmStepBwd {
+  const float* dA_next; long long sdn;  // d(pre-activations) of step t+1 [B, 4 Ch, hw]
+  const u32x4* wpd;                     // packed fp16x3 data-gradient operand of W_h (k = 4 Ch gate channels, outputs = Ch)
+  const float* winv;
+  float* gates; long long sg;           // step t: activations in, d(pre-activations) out
+  const float* c_prev; long long scp;   // c_{t-1} (nullable: t = 0)
+  const float* c_cur; long long scc;    // c_t
+  const float* dh_ext; long long sde;   // external gradient wrt h_t (nullable)
+  float* dc;                            // [B, Ch, hw] carried dL/dc
+  int B, Ch, H, W;
+};
+
+template <int PH>     // phases of two stages per wave: 4 Ch = 8 waves * PH * 32 gate channels
+__global__ __launch_bounds__(512, 1) void lstm_step_bwd_kernel(LstmStepBwd a) {
+  extern __shared__ u32x4 lds[];
+  __shared__ unsigned smax;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int H = a.H, W = a.W, HW = H * W, Ch = a.Ch, G = 4 * Ch;
+  const int NOCT = G >> 3, nsteps = G >> 4;
+  const int hb = blockIdx.x, b = blockIdx.y;
+  const int ZREC = 2 * NOCT * HW;                 // index of the all-zero record
+  if (tid == 0) smax = 0u;
+  if (tid == 1) lds[ZREC] = u32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+
+  // ---- stage dA_{t+1}[b]: pass 1 maximum, pass 2 (L2-hot re-read) scale + split ----
+  const float* src = a.dA_next + (long long)b * a.sdn;
+  {
+    float m = 0.f;
+    for (int e = tid; e < NOCT * HW; e += 512) {
+      const int oct = e / HW, p = e - oct * HW;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(src[(long long)(oct * 8 + j) * HW + p]));
+    }
+    m = wave_max_nonneg(m);
+    if (lane == 0) atomicMax(&smax, __float_as_uint(m));
+  }
+  __syncthreads();
+  const unsigned be = max((smax >> 23) & 0xffu, 13u);
+  const float sc = __uint_as_float((267u - be) << 23);                       // largest |dA| -> [2^13, 2^14)
+  const float inv = (smax == 0u) ? 0.f : __uint_as_float((be - 13u) << 23) * a.winv[0];
+  for (int e = tid; e < NOCT * HW; e += 512) {
+    const int oct = e / HW, p = e - oct * HW;
+    u32x4 ph, pl;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned hi, lo;
+      split2_pair_f16(src[(long long)(oct * 8 + 2 * q) * HW + p] * sc, src[(long long)(oct * 8 + 2 * q + 1) * HW + p] * sc, hi, lo);
+      ph[q] = hi; pl[q] = lo;
+    }
+    lds[oct * HW + p] = ph;
+    lds[(NOCT + oct) * HW + p] = pl;
+  }
+  // per-lane tap table: record offset (inside one octet plane) of the input pixel of every tap, or -1 (outside the image)
+  int toff[2][9];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int col = t * 32 + l31;
+    const int y = col / W, x = col - y * W;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+      toff[t][tap] = (col < HW && yy >= 0 && yy < H && xx >= 0 && xx < W) ? yy * W + xx : -1;
+    }
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  __syncthreads();
+
+  const long long piece_stride = (long long)nsteps * 9 * 2 * Ch;      // (outputs = Ch, a multiple of 32)
+  const int arow = hb * 32 + l31;
+#pragma unroll 1
+  for (int ph_ = 0; ph_ < PH; ++ph_) {
+    f16x8 af[2][9][2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+          const int step = (wave * PH + ph_) * 2 + st;
+          af[st][tap][pc] = __builtin_bit_cast(f16x8, a.wpd[pc * piece_stride + ((long long)(step * 9 + tap) * 2 + half) * Ch + arow]);
+        }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const int oct = ((wave * PH + ph_) * 2 + st) * 2 + half;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int o = toff[t][tap];
+          const f16x8 bh = __builtin_bit_cast(f16x8, lds[o >= 0 ? oct * HW + o : ZREC]);
+          const f16x8 bl = __builtin_bit_cast(f16x8, lds[o >= 0 ? (NOCT + oct) * HW + o : ZREC]);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[st][tap][1], bh, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[st][tap][0], bl, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[st][tap][0], bh, acc[t], 0, 0, 0);
+        }
+    }
+  }
+
+  // ---- reduce the 8 partial accumulators through LDS; wave w finishes registers [(w >> 1) * 4, +4) of tile w & 1 ----
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(lds);          // [8][2][16][64]
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((wave * 2 + t) * 16 + r) * 64 + lane] = acc[t][r];
+  __syncthreads();
+  const int t = wave & 1, r0 = (wave >> 1) * 4;
+  const int col = t * 32 + l31;
+  if (col < HW) {
+    const long long per = (long long)Ch * HW;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int r = r0 + jj;
+      float dh = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < 8; ++w2) dh += red[((w2 * 2 + t) * 16 + r) * 64 + lane];
+      dh *= inv;
+      const int ch = hb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const long long e = (long long)ch * HW + col;
+      if (a.dh_ext) dh += a.dh_ext[(long long)b * a.sde + e];
+      float* gp = a.gates + (long long)b * a.sg + e;
+      const float i = gp[0], f = gp[per], o = gp[2 * per], g = gp[3 * per];
+      const float tc = tanhf(a.c_cur[(long long)b * a.scc + e]);
+      const float cp = a.c_prev ? a.c_prev[(long long)b * a.scp + e] : 0.f;
+      const long long di = (long long)b * per + e;
+      const float dct = a.dc[di] + dh * o * (1.f - tc * tc);
+      const float d_o = dh * tc;
+      gp[0] = dct * g * i * (1.f - i);
+      gp[per] = dct * cp * f * (1.f - f);
+      gp[2 * per] = d_o * o * (1.f - o);
+      gp[3 * per] = dct * i * (1.f - g * g);
+      a.dc[di] = dct * f;
+    }
+  }
+}
+
 struct StepGeo {
   int nw, nstg, nt, s;
   size_t lds;
@@ -218,6 +370,37 @@ int cm_lstm_step_fwd(const float* hprev, long long sh, const void* wph, const fl
   else if (g.nw == 4 && g.nstg == 2) { if (g.nt == 1) CM_STEP(4, 2, 1); else CM_STEP(4, 2, 2); }
   else { if (g.nt == 1) CM_STEP(8, 2, 1); else CM_STEP(8, 2, 2); }
 #undef CM_STEP
+  CM_CHECK_LAUNCH();
+  return 0;
+}
+
+int cm_lstm_step_bwd_supported(int b, int ch, int h, int w) {
+  // 4 ch = 8 waves x PH phases x 32 gate channels (PH = 1: ch 64, PH = 2: ch 128); the sample's dA fits LDS un-haloed
+  if (b <= 0 || (ch != 64 && ch != 128) || h * w > 64 || h * w < 1) return 0;
+  const size_t xl = ((size_t)2 * (4 * ch / 8) * h * w + 1) * 16, rd = (size_t)8 * 2 * 16 * 64 * 4;
+  return (xl > rd ? xl : rd) <= 150 * 1024;
+}
+
+int cm_lstm_step_bwd(const float* dA_next, long long sdn, const void* wpd, const float* wscale_inv, float* gates,
+                     long long sg, const float* c_prev, long long scp, const float* c_cur, long long scc,
+                     const float* dh_ext, long long sde, float* dc, int b, int ch, int h, int w, cm_stream stream) {
+  if (!cm_lstm_step_bwd_supported(b, ch, h, w) || !dA_next || !wpd || !wscale_inv || !gates || !c_cur || !dc) return -22;
+  LstmStepBwd a;
+  a.dA_next = dA_next; a.sdn = sdn; a.wpd = (const u32x4*)wpd; a.winv = wscale_inv; a.gates = gates; a.sg = sg;
+  a.c_prev = c_prev; a.scp = scp; a.c_cur = c_cur; a.scc = scc; a.dh_ext = dh_ext; a.sde = sde; a.dc = dc;
+  a.B = b; a.Ch = ch; a.H = h; a.W = w;
+  const size_t xl = ((size_t)2 * (4 * ch / 8) * h * w + 1) * 16, rd = (size_t)8 * 2 * 16 * 64 * 4;
+  const size_t lds = xl > rd ? xl : rd;
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)lstm_step_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+    hipFuncSetAttribute((const void*)lstm_step_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+    (void)hipGetLastError();
+    attr = true;
+  }
+  const dim3 grid(ch / 32, b);
+  if (ch == 64) lstm_step_bwd_kernel<1><<<grid, 512, lds, (hipStream_t)stream>>>(a);
+  else lstm_step_bwd_kernel<2><<<grid, 512, lds, (hipStream_t)stream>>>(a);
   CM_CHECK_LAUNCH();
   return 0;
 }

@@ -604,10 +604,17 @@ def convlstm_bwd(p: Params, pk, g: Params, gw: Params, ss, ctx: _LstmCtx, dbott:
     pbuf = None
     if before_chain is not None:
         before_chain()
+    fused = "lstm.h/d" in pk.pkh and ops.lstm_step_bwd_supported(B, ch, h8, w8)
     for t in range(T - 1, -1, -1):
         ext = None
         if dh_all_steps is not None:
             ext = dh_all_steps[:, t]
+        if fused and t < T - 1:
+            # recurrent data gradient of step t+1's dA + gate backward of step t in ONE launch (csrc/lstm_step.hip)
+            ops.lstm_step_bwd(gx[:, t + 1], pk.pkh["lstm.h/d"], pk.winv["lstm.h/d"], gx[:, t],
+                              call[:, t - 1] if t > 0 else None, call[:, t], ext, dc)
+            pk.uses_fp32.setdefault("lstm.h/d", False)
+            continue
         if t == T - 1 and dbott is not None:
             if ext is None:
                 ext = dbott
@@ -615,7 +622,7 @@ def convlstm_bwd(p: Params, pk, g: Params, gw: Params, ss, ctx: _LstmCtx, dbott:
                 ext = ext + dbott          # (test-only combination; the model passes dbott alone)
         # dh_t = external part + recurrent part (either may be absent); dc carries dL/dc_t
         ops.lstm_gates_bwd(gx[:, t], call[:, t - 1] if t > 0 else None, call[:, t], ext, dhrec, dc, first=(t == T - 1))
-        if t > 0:
+        if t > 0 and not fused:
             dhrec = pk.conv_parts("lstm.h/d", gx[:, t], ch, parts=pbuf) if dh_rec_all is None else None
             if dhrec is not None:
                 pbuf = dhrec[0]

@@ -727,6 +727,24 @@ def lstm_step_fwd(hprev, wph, winv, gates, c_prev, c_out, h_out):
                                _stream()), "lstm_step_fwd")
 
 
+def lstm_step_bwd_supported(b, ch, h, w):
+    return LSTM_STEP and bool(lib.cm_lstm_step_bwd_supported(b, ch, h, w))
+
+
+def lstm_step_bwd(dA_next, wpd, winv, gates, c_prev, c_cur, dh_ext, dc):
+    """One BPTT step t < T-1 in one launch: recurrent data gradient of dA_next + gate backward of this step
+    (cm_lstm_step_bwd); ``gates`` turns from activations into d(pre-activations), ``dc`` is updated in place."""
+    b, ch4, h, w = gates.shape
+    ch = ch4 // 4
+    for t in (dA_next, gates, c_prev, c_cur, dh_ext):
+        if t is not None and (t.stride(3) != 1 or t.stride(2) != w or t.stride(1) != h * w):
+            raise RuntimeError("lstm_step_bwd needs dense HxW planes with channel stride H*W")
+    check(lib.cm_lstm_step_bwd(_p(dA_next), dA_next.stride(0), _p(wpd), _p(winv), _p(gates), gates.stride(0), _p(c_prev),
+                               0 if c_prev is None else c_prev.stride(0), _p(c_cur), c_cur.stride(0), _p(dh_ext),
+                               0 if dh_ext is None else dh_ext.stride(0), _p(_contig(dc)), b, ch, h, w, _stream()),
+          "lstm_step_bwd")
+
+
 def lstm_gates_bwd(gates, c_prev, c_cur, dh_a, dh_b, dc, first):
     """dh_b: a tensor [B, ch, h, w], None, or (stack [>= k, B, ch, h, w], k) from conv3x3_parts."""
     b, ch4, h, w = gates.shape

@@ -571,11 +571,15 @@ def test_side_stream_overlap_three_steps(amd, monkeypatch, use_graph):
     # after several Adam steps are not compared: Adam's per-element normalisation turns rounding-level gradient
     # differences on near-zero elements into lr-sized steps.)
     lay = m._build_layout()
+    ga, gb = res[True][1], res[False][1]
+    big = max(gb[o:o + n].norm().item() for k, (o, n, _s) in lay.items() if o + n <= gb.numel())
     for k, (o, n, _s) in lay.items():
-        if o + n <= res[False][1].numel():
-            # (summation order of the float atomics differs between the schedules; the SE weight gradients are ~1e-8
-            #  sums of strongly cancelling terms over the two micro-batches: 7.5e-5 observed there, everything else <= 3e-6)
-            assert rel_l2(res[True][1][o:o + n], res[False][1][o:o + n]) < 2e-4, k
+        if o + n <= gb.numel():
+            # (summation order of the float atomics differs between the schedules.  On this task some tensors' gradients --
+            #  SE weights, GroupNorm scales of the deep levels -- are ~1e-8 sums of strongly cancelling ~1e-5 terms: their
+            #  own norm is not a meaningful yardstick (2.5e-4 of it observed), the step's gradient scale is)
+            err = (ga[o:o + n] - gb[o:o + n]).norm().item() / max(gb[o:o + n].norm().item(), 1e-3 * big)
+            assert err < 5e-5, (k, err)
 
 
 @pytest.mark.parametrize("name", ["cfg3_b32_checksums.npz", "cfg5_b16_checksums.npz"])

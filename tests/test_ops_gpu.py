@@ -640,6 +640,53 @@ def test_lstm_step_fused(ops, case):
     assert torch.all(gxd[:, 0] == 0) and torch.all(gxd[:, 2] == 0) and torch.all(cout[:, 0] == 0)   # neighbours untouched
 
 
+@pytest.mark.parametrize("case", [(16, 128, 6, 9), (3, 64, 6, 9), (2, 128, 4, 6), (5, 128, 8, 8)])
+def test_lstm_step_bwd_fused(ops, case):
+    """cm_lstm_step_bwd (recurrent data gradient + gate backward in one launch) vs autograd through two ConvLSTMCell steps
+    in float64 (oracle.convlstm_cell): d(pre-activations) of step t and the carried dL/dc, given step t+1's."""
+    b, ch, h, w = case
+    cx = 2 * ch
+    assert ops.lstm_step_bwd_supported(b, ch, h, w)
+    torch.manual_seed(6)
+    wl = (torch.randn(4 * ch, cx + ch, 3, 3) * (1.0 / ((cx + ch) * 9) ** 0.5)).double()
+    bl = (torch.randn(4 * ch) * 0.1).double()
+    x0, x1 = torch.randn(b, cx, h, w).double(), torch.randn(b, cx, h, w).double()
+    hm = torch.tanh(torch.randn(b, ch, h, w)).double().requires_grad_()       # h_{t-1}
+    cm = torch.randn(b, ch, h, w).double().requires_grad_()                   # c_{t-1}
+    ext_t = torch.randn(b, ch, h, w).double()
+    if b > 1:
+        ext_t[1] *= 1e-6                                 # samples of very different gradient magnitude
+    # float64 reference: pre-activations as leaves so that their gradients (dA_t, dA_{t+1}) can be read
+    def cell(x, hp, cp):
+        pre = F.conv2d(torch.cat([x, hp], 1), wl, bl, padding=1)
+        pre.retain_grad()
+        i, f, o, g = pre.chunk(4, 1)
+        i, f, o, g = torch.sigmoid(i), torch.sigmoid(f), torch.sigmoid(o), torch.tanh(g)
+        c = f * cp + i * g
+        return o * torch.tanh(c), c, pre, torch.cat([i, f, o, g], 1)
+    h0, c0, pre0, act0 = cell(x0, hm, cm)
+    h1, c1, pre1, act1 = cell(x1, h0, c0)
+    dh1 = torch.randn(b, ch, h, w).double()
+    ((h1 * dh1).sum() + (h0 * ext_t).sum()).backward()
+    dA1, dA0 = pre1.grad, pre0.grad
+    # device: step t+1 already holds dA1 and the carried dc = dL/dc_t = dct_{t+1} * f_{t+1}
+    f1, o1 = act1[:, ch:2 * ch], act1[:, 2 * ch:3 * ch]
+    tc1 = torch.tanh(c1)
+    dct1 = dh1 * o1 * (1 - tc1 * tc1)
+    dc = dev((dct1 * f1).float())
+    T = 2
+    gx = torch.zeros(b, T, 4 * ch, h, w)
+    gx[:, 1] = dA1.float()
+    gx[:, 0] = act0.float()
+    gxd = dev(gx)
+    call = dev(torch.stack([c0.detach().float(), c1.detach().float()], 1))
+    wpd, winv = ops.pack_conv3x3_h3(dev(wl.float()), c_off=cx, cin=ch, dgrad=True)
+    ops.lstm_step_bwd(gxd[:, 1], wpd, winv, gxd[:, 0], dev(cm.detach().float()), call[:, 0], dev(ext_t.float()), dc)
+    assert rel_l2(gxd[:, 0], dA0) < 5e-6
+    assert rel_l2(dc, cm.grad) < 5e-6                    # dL/dc_{t-1}
+    assert torch.equal(gxd[:, 1].cpu(), dA1.float())     # the neighbour slice is only read
+
+
 def test_conv_partial_slices_and_lstm_gates_parts(ops):
     """The ConvLSTM recurrence's launch form: cm_conv3x3_h3 with config bit 29 STORES its reduction shares as slices
     (no zero fill, no atomics); the gate kernels add them while reading (cm_lstm_gates_fwd_parts / _bwd_parts).
