@@ -195,14 +195,39 @@ __global__ __launch_bounds__(512, 1) void lstm_step_bwd_kernel(LstmStepBwd a) {
   if (tid == 1) lds[ZREC] = u32x4{0u, 0u, 0u, 0u};
   __syncthreads();
 
-  // ---- stage dA_{t+1}[b]: pass 1 maximum, pass 2 (L2-hot re-read) scale + split ----
+  // ---- this wave's weight fragments of phase 0: issued FIRST so that they fly while dA is staged ----
+  const long long piece_stride = (long long)nsteps * 9 * 2 * Ch;      // (outputs = Ch, a multiple of 32)
+  const int arow = hb * 32 + l31;
+  f16x8 af[2][9][2];
+  auto load_phase = [&](int ph_) {
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+          const int step = (wave * PH + ph_) * 2 + st;
+          af[st][tap][pc] = __builtin_bit_cast(f16x8, a.wpd[pc * piece_stride + ((long long)(step * 9 + tap) * 2 + half) * Ch + arow]);
+        }
+  };
+  load_phase(0);
+
+  // ---- stage dA_{t+1}[b]: one read into registers, the sample's maximum, then scale + split into LDS ----
   const float* src = a.dA_next + (long long)b * a.sdn;
+  constexpr int MAXIT = 8;                       // records per thread: (4 Ch / 8) * hw <= 8 * 512 (host check)
+  float v[MAXIT][8];
   {
     float m = 0.f;
-    for (int e = tid; e < NOCT * HW; e += 512) {
-      const int oct = e / HW, p = e - oct * HW;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(src[(long long)(oct * 8 + j) * HW + p]));
+    for (int it = 0; it < MAXIT; ++it) {
+      const int e = tid + it * 512;
+      const bool ok = e < NOCT * HW;
+      const int oct = ok ? e / HW : 0, p = ok ? e - oct * HW : 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[it][j] = ok ? src[(long long)(oct * 8 + j) * HW + p] : 0.f;
+        m = fmaxf(m, fabsf(v[it][j]));
+      }
     }
     m = wave_max_nonneg(m);
     if (lane == 0) atomicMax(&smax, __float_as_uint(m));
@@ -211,17 +236,21 @@ __global__ __launch_bounds__(512, 1) void lstm_step_bwd_kernel(LstmStepBwd a) {
   const unsigned be = max((smax >> 23) & 0xffu, 13u);
   const float sc = __uint_as_float((267u - be) << 23);                       // largest |dA| -> [2^13, 2^14)
   const float inv = (smax == 0u) ? 0.f : __uint_as_float((be - 13u) << 23) * a.winv[0];
-  for (int e = tid; e < NOCT * HW; e += 512) {
-    const int oct = e / HW, p = e - oct * HW;
-    u32x4 ph, pl;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      unsigned hi, lo;
-      split2_pair_f16(src[(long long)(oct * 8 + 2 * q) * HW + p] * sc, src[(long long)(oct * 8 + 2 * q + 1) * HW + p] * sc, hi, lo);
-      ph[q] = hi; pl[q] = lo;
+  for (int it = 0; it < MAXIT; ++it) {
+    const int e = tid + it * 512;
+    if (e < NOCT * HW) {
+      const int oct = e / HW, p = e - oct * HW;
+      u32x4 ph, pl;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        unsigned hi, lo;
+        split2_pair_f16(v[it][2 * q] * sc, v[it][2 * q + 1] * sc, hi, lo);
+        ph[q] = hi; pl[q] = lo;
+      }
+      lds[oct * HW + p] = ph;
+      lds[(NOCT + oct) * HW + p] = pl;
     }
-    lds[oct * HW + p] = ph;
-    lds[(NOCT + oct) * HW + p] = pl;
   }
   // per-lane tap table: record offset (inside one octet plane) of the input pixel of every tap, or -1 (outside the image)
   int toff[2][9];
@@ -242,20 +271,10 @@ __global__ __launch_bounds__(512, 1) void lstm_step_bwd_kernel(LstmStepBwd a) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   __syncthreads();
 
-  const long long piece_stride = (long long)nsteps * 9 * 2 * Ch;      // (outputs = Ch, a multiple of 32)
-  const int arow = hb * 32 + l31;
-#pragma unroll 1
+#pragma unroll
   for (int ph_ = 0; ph_ < PH; ++ph_) {
-    f16x8 af[2][9][2];
-#pragma unroll
-    for (int st = 0; st < 2; ++st)
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-        for (int pc = 0; pc < 2; ++pc) {
-          const int step = (wave * PH + ph_) * 2 + st;
-          af[st][tap][pc] = __builtin_bit_cast(f16x8, a.wpd[pc * piece_stride + ((long long)(step * 9 + tap) * 2 + half) * Ch + arow]);
-        }
+    if (ph_ > 0) load_phase(ph_);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the whole phase's fragments were issued back to back above
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
       const int oct = ((wave * PH + ph_) * 2 + st) * 2 + half;
@@ -376,7 +395,7 @@ int cm_lstm_step_fwd(const float* hprev, long long sh, const void* wph, const fl
 
 int cm_lstm_step_bwd_supported(int b, int ch, int h, int w) {
   // 4 ch = 8 waves x PH phases x 32 gate channels (PH = 1: ch 64, PH = 2: ch 128); the sample's dA fits LDS un-haloed
-  if (b <= 0 || (ch != 64 && ch != 128) || h * w > 64 || h * w < 1) return 0;
+  if (b <= 0 || (ch != 64 && ch != 128) || h * w > 64 || h * w < 1 || (4 * ch / 8) * h * w > 8 * 512) return 0;
   const size_t xl = ((size_t)2 * (4 * ch / 8) * h * w + 1) * 16, rd = (size_t)8 * 2 * 16 * 64 * 4;
   return (xl > rd ? xl : rd) <= 150 * 1024;
 }

@@ -727,8 +727,15 @@ def lstm_step_fwd(hprev, wph, winv, gates, c_prev, c_out, h_out):
                                _stream()), "lstm_step_fwd")
 
 
+# The backward step kernel (cm_lstm_step_bwd) is built and parity-tested but OFF by default: its reduction is 4x deeper than
+# the forward's (K = 4 Ch * 9) for a quarter of the output rows, so each of its 64 workgroups streams 590 KB of weight
+# fragments and runs 216 MFMAs per wave with nothing beside it on the CU -- 20.3 us against 17.3 us for the K-split
+# partial-slices launch + gate kernel it would replace (tools/tail_bench.py; step: 8247 vs 8268 samples/s same box).
+LSTM_STEP_BWD = os.environ.get("CM_LSTM_STEP_BWD", "0") != "0"
+
+
 def lstm_step_bwd_supported(b, ch, h, w):
-    return LSTM_STEP and bool(lib.cm_lstm_step_bwd_supported(b, ch, h, w))
+    return LSTM_STEP and LSTM_STEP_BWD and bool(lib.cm_lstm_step_bwd_supported(b, ch, h, w))
 
 
 def lstm_step_bwd(dA_next, wpd, winv, gates, c_prev, c_cur, dh_ext, dc):

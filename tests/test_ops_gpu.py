@@ -641,11 +641,12 @@ def test_lstm_step_fused(ops, case):
 
 
 @pytest.mark.parametrize("case", [(16, 128, 6, 9), (3, 64, 6, 9), (2, 128, 4, 6), (5, 128, 8, 8)])
-def test_lstm_step_bwd_fused(ops, case):
+def test_lstm_step_bwd_fused(ops, case, monkeypatch):
     """cm_lstm_step_bwd (recurrent data gradient + gate backward in one launch) vs autograd through two ConvLSTMCell steps
     in float64 (oracle.convlstm_cell): d(pre-activations) of step t and the carried dL/dc, given step t+1's."""
     b, ch, h, w = case
     cx = 2 * ch
+    monkeypatch.setattr(ops, "LSTM_STEP_BWD", True)      # (off by default: measured slower than the launch pair, see ops)
     assert ops.lstm_step_bwd_supported(b, ch, h, w)
     torch.manual_seed(6)
     wl = (torch.randn(4 * ch, cx + ch, 3, 3) * (1.0 / ((cx + ch) * 9) ** 0.5)).double()

@@ -20,13 +20,14 @@ from climate_amd.model import get_model  # noqa: E402
 from climate_amd.trainer import HotPathTrainer  # noqa: E402
 
 DEFAULTS = dict(tail=ops.BLOCK_TAIL, tail_min=ops.BLOCK_TAIL_MIN_N, lstm=ops.LSTM_STEP, ow=engine.OVERLAP_WGRAD,
-                gn=ops.GN_EPILOGUE)
+                gn=ops.GN_EPILOGUE, lstmb=ops.LSTM_STEP_BWD)
 
 
 def apply(v):
     ops.BLOCK_TAIL, ops.BLOCK_TAIL_MIN_N, ops.LSTM_STEP, engine.OVERLAP_WGRAD = (DEFAULTS["tail"], DEFAULTS["tail_min"],
                                                                                  DEFAULTS["lstm"], DEFAULTS["ow"])
     ops.GN_EPILOGUE = DEFAULTS["gn"]
+    ops.LSTM_STEP_BWD = DEFAULTS["lstmb"]
     micro = None
     if v == "tail_off":
         ops.BLOCK_TAIL = False
@@ -38,6 +39,8 @@ def apply(v):
         engine.OVERLAP_WGRAD = True
     elif v == "micro1":
         micro = 1
+    elif v == "lstm_bwd_off":
+        ops.LSTM_STEP_BWD = False
     elif v == "gn_epi_off":
         ops.GN_EPILOGUE = False
     elif v != "base":

@@ -100,6 +100,27 @@ def lstm_case(b, ch, h, w, out):
     t = [graph_time(f) for f in (chain, fused)]
     out.write(f"lstm  B={b:3d} Ch={ch:3d} {h}x{w}: projection (partial slices) + gates {t[0]:6.1f} us  fused step {t[1]:6.1f} us\n")
     out.flush()
+    if not ops.lstm_step_bwd_supported(b, ch, h, w):
+        return
+    # backward step: gate backward (with the previous step's partial slices) + recurrent data gradient as partial slices
+    wpd, wdinv = ops.pack_conv3x3_h3(wl, c_off=cx, cin=ch, dgrad=True)
+    dA_next = torch.randn(b, 4 * ch, h, w, device="cuda")
+    act = torch.rand(b, 4 * ch, h, w, device="cuda")
+    dc = torch.randn(b, ch, h, w, device="cuda")
+    dbuf = [None]
+
+    def chain_b():
+        parts = ops.conv3x3_parts(dA_next, ch, wpd, wdinv, parts=dbuf[0])
+        dbuf[0] = parts[0]
+        ops.lstm_gates_bwd(act, cp, co, None, parts, dc, first=False)
+
+    def fused_b():
+        ops.lstm_step_bwd(dA_next, wpd, wdinv, act, cp, co, None, dc)
+
+    t = [graph_time(f) for f in (chain_b, fused_b)]
+    out.write(f"lstm  B={b:3d} Ch={ch:3d} {h}x{w}: backward: data gradient (partial slices) + gate backward {t[0]:6.1f} us  "
+              f"fused step {t[1]:6.1f} us\n")
+    out.flush()
 
 
 if __name__ == "__main__":
