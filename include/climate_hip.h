@@ -390,6 +390,14 @@ int cm_layernorm_fwd(const float* x, const float* resid, const float* gamma, con
 /* ds = gradient wrt sum_in (flows to both residual branches); dgamma / dbeta ACCUMULATED.                         */
 int cm_layernorm_bwd(const float* sum_in, const float* stats, const float* gamma, const float* dy, float* ds,
                      float* dgamma, float* dbeta, int m, int e, cm_stream stream);
+/* cm_layernorm_bwd with the side outputs of the sublayer that fed this LayerNorm through x + dropout(sublayer(x))
+ * (nn.TransformerEncoderLayer._sa_block / _ff_block, src/cnn_transformer.py:27-31): ds_drop (nullable) = ds times the
+ * dropout multipliers of (rng, site, drop_p) (element index m*e + column; drop_p 0: a copy is NOT written, pass NULL) and
+ * dbias (nullable, ACCUMULATED) += column sums of that gradient = the bias gradient of the sublayer's last linear layer.
+ * Replaces a cm_dropout + a cm_rowgroup_sum launch. */
+int cm_layernorm_bwd_sublayer(const float* sum_in, const float* stats, const float* gamma, const float* dy, float* ds,
+                              float* dgamma, float* dbeta, float* ds_drop, float* dbias, const unsigned* rng,
+                              unsigned site, float drop_p, int m, int e, cm_stream stream);
 /* Multi-head self-attention core of nn.MultiheadAttention (batch_first, no mask, dropout off): qkv [b*s, 3e] = packed
  * in_proj output; p [b, h, s, s] = softmax(q k^T / sqrt(d)) (kept for the backward); o [b*s, e] = p v, heads
  * concatenated.  head_dim e/h in {8, 16, 32}, s <= 256.                                                           */

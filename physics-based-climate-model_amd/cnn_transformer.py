@@ -133,19 +133,18 @@ def backward(p: Dict[str, Tensor], g: Dict[str, Tensor], sv, n_heads: int, dpred
         drop = getattr(sv, "drop", None)
         dr = [None] * 4 if drop is None else [(drop[0], 4 * i + k, drop[1]) for k in range(4)]
         keep_scale = 1.0 if drop is None else 1.0 / (1.0 - drop[1])
-        ds2 = ops.layernorm_bwd(s2, st2, p[q + "norm2.weight"], dt, g[q + "norm2.weight"], g[q + "norm2.bias"])
-        # ds2 = gradient wrt (t1 + dropout(m2)): the residual branch takes it as it is, the MLP branch through the mask
-        dm2 = ds2 if drop is None else ops.dropout(ds2, dr[3])
-        ops.rowgroup_sum(dm2, g[q + "linear2.bias"].view(1, E))
+        # ds2 = gradient wrt (t1 + dropout(m2)): the residual branch takes it as it is, the MLP branch through the mask;
+        # the same launch adds the column sums of the masked gradient into linear2's bias gradient
+        ds2, dm2 = ops.layernorm_bwd(s2, st2, p[q + "norm2.weight"], dt, g[q + "norm2.weight"], g[q + "norm2.bias"],
+                                     drop=dr[3], dbias=g[q + "linear2.bias"])
         _wgrad(dm2, h1, g[q + "linear2.weight"], E, mlp, M)
         # through linear2, the MLP dropout and the ReLU: h1 is the DROPPED activation, so h1 > 0 <=> kept and positive
         dh1 = ops.gemm(dm2, p[q + "linear2.weight"], M, mlp, E, trans_b=True, mask=h1, mask_scale=keep_scale)
         ops.rowgroup_sum(dh1, g[q + "linear1.bias"].view(1, mlp))
         _wgrad(dh1, t1, g[q + "linear1.weight"], mlp, E, M)
         dt1 = ops.gemm(dh1, p[q + "linear1.weight"], M, E, mlp, trans_b=True, resid=ds2, res_rows=M)   # + residual branch
-        ds1 = ops.layernorm_bwd(s1, st1, p[q + "norm1.weight"], dt1, g[q + "norm1.weight"], g[q + "norm1.bias"])
-        da = ds1 if drop is None else ops.dropout(ds1, dr[1])
-        ops.rowgroup_sum(da, g[q + "self_attn.out_proj.bias"].view(1, E))
+        ds1, da = ops.layernorm_bwd(s1, st1, p[q + "norm1.weight"], dt1, g[q + "norm1.weight"], g[q + "norm1.bias"],
+                                    drop=dr[1], dbias=g[q + "self_attn.out_proj.bias"])
         _wgrad(da, o, g[q + "self_attn.out_proj.weight"], E, E, M)
         d_o = ops.gemm(da, p[q + "self_attn.out_proj.weight"], M, E, E, trans_b=True)
         dqkv = ops.attention_bwd(qkv, P, d_o, B, S, E, n_heads, drop=dr[0], o=o)

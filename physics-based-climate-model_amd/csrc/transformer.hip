@@ -50,18 +50,24 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // ds = rstd * (dy*gamma - mean(dy*gamma) - xhat * mean(dy*gamma*xhat)); dgamma += sum dy*xhat; dbeta += sum dy.
 // Workgroup = 4 rows (one per wave) x ROWS_PER_WG row groups; the parameter gradients are combined through LDS and
 // added with one atomic per column and workgroup.
+// Side outputs (both nullable) for the sublayer that fed this LayerNorm through x + dropout(sublayer(x)): ds_drop = ds times
+// the dropout multipliers of (rng, site, p) -- the gradient wrt the sublayer's output -- and dbias += column sums of that
+// gradient (the bias gradient of the sublayer's last linear layer): saves a cm_dropout and a cm_rowgroup_sum launch.
 template <int VPL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ s, const float* __restrict__ stats,
                                                      const float* __restrict__ gamma, const float* __restrict__ dy,
                                                      float* __restrict__ ds, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int M, int E, int rows_per_wg) {
-  extern __shared__ float sh[];              // [2][E]
-  for (int i = threadIdx.x; i < 2 * E; i += 256) sh[i] = 0.f;
+                                                     float* __restrict__ dbeta, int M, int E, int rows_per_wg,
+                                                     float* __restrict__ ds_drop, float* __restrict__ dbias,
+                                                     const unsigned* __restrict__ rng, unsigned site, float drop_p) {
+  extern __shared__ float sh[];              // [3][E]
+  for (int i = threadIdx.x; i < 3 * E; i += 256) sh[i] = 0.f;
   __syncthreads();
+  const DropSite drop = cm_drop_site(rng, site, drop_p);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float ag[VPL], ab[VPL];
+  float ag[VPL], ab[VPL], abias[VPL];
 #pragma unroll
-  for (int i = 0; i < VPL; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
+  for (int i = 0; i < VPL; ++i) { ag[i] = 0.f; ab[i] = 0.f; abias[i] = 0.f; }
   const int r0 = blockIdx.x * rows_per_wg;
   for (int row = r0 + wv; row < min(M, r0 + rows_per_wg); row += 4) {
     const float mean = stats[2 * row], rstd = stats[2 * row + 1];
@@ -83,18 +89,31 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ s
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       const int c = lane + 64 * i;
-      if (c < E) ds[(long long)row * E + c] = rstd * (g[i] - s1 - xh[i] * s2);
+      if (c < E) {
+        const float d = rstd * (g[i] - s1 - xh[i] * s2);
+        ds[(long long)row * E + c] = d;
+        if (ds_drop || dbias) {
+          const float dd = drop.thresh ? d * cm_drop_mul(drop, (unsigned)row * (unsigned)E + (unsigned)c) : d;
+          if (ds_drop) ds_drop[(long long)row * E + c] = dd;
+          abias[i] += dd;
+        }
+      }
     }
   }
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     const int c = lane + 64 * i;
-    if (c < E) { atomicAdd(&sh[c], ag[i]); atomicAdd(&sh[E + c], ab[i]); }
+    if (c < E) {
+      atomicAdd(&sh[c], ag[i]);
+      atomicAdd(&sh[E + c], ab[i]);
+      if (dbias) atomicAdd(&sh[2 * E + c], abias[i]);
+    }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < E; c += 256) {
     unsafeAtomicAdd(dgamma + c, sh[c]);
     unsafeAtomicAdd(dbeta + c, sh[E + c]);
+    if (dbias) unsafeAtomicAdd(dbias + c, sh[2 * E + c]);
   }
 }
 
@@ -431,18 +450,33 @@ int cm_layernorm_fwd(const float* x, const float* resid, const float* gamma, con
   return 0;
 }
 
-int cm_layernorm_bwd(const float* sum_in, const float* stats, const float* gamma, const float* dy, float* ds,
-                     float* dgamma, float* dbeta, int m, int e, cm_stream stream) {
+static int ln_bwd_launch(const float* sum_in, const float* stats, const float* gamma, const float* dy, float* ds,
+                         float* dgamma, float* dbeta, float* ds_drop, float* dbias, const unsigned* rng, unsigned site,
+                         float drop_p, int m, int e, cm_stream stream) {
   if (m <= 0 || e <= 0 || e > 1024 || !sum_in || !stats || !dy || !ds) return -22;
+  if (drop_p < 0.f || drop_p > 1.f || (long long)m * e > 0xffffffffLL) return -22;
+  if (drop_p == 0.f) rng = nullptr;
   hipStream_t st = (hipStream_t)stream;
   static const int rpw_env = getenv("CM_LN_BWD_ROWS") ? atoi(getenv("CM_LN_BWD_ROWS")) : 32;
   const int rpw = rpw_env >= 4 ? rpw_env / 4 * 4 : 4, grid = cdiv(m, rpw), vpl = cdiv(e, 64);
-  const size_t lds = 2 * (size_t)e * sizeof(float);
-#define LNB(V) ln_bwd_kernel<V><<<grid, 256, lds, st>>>(sum_in, stats, gamma, dy, ds, dgamma, dbeta, m, e, rpw)
+  const size_t lds = 3 * (size_t)e * sizeof(float);
+#define LNB(V) ln_bwd_kernel<V><<<grid, 256, lds, st>>>(sum_in, stats, gamma, dy, ds, dgamma, dbeta, m, e, rpw, ds_drop, dbias, rng, site, drop_p)
   if (vpl <= 1) LNB(1); else if (vpl <= 2) LNB(2); else if (vpl <= 4) LNB(4); else if (vpl <= 8) LNB(8); else LNB(16);
 #undef LNB
   CM_CHECK_LAUNCH();
   return 0;
+}
+
+int cm_layernorm_bwd(const float* sum_in, const float* stats, const float* gamma, const float* dy, float* ds,
+                     float* dgamma, float* dbeta, int m, int e, cm_stream stream) {
+  return ln_bwd_launch(sum_in, stats, gamma, dy, ds, dgamma, dbeta, nullptr, nullptr, nullptr, 0, 0.f, m, e, stream);
+}
+
+int cm_layernorm_bwd_sublayer(const float* sum_in, const float* stats, const float* gamma, const float* dy, float* ds,
+                              float* dgamma, float* dbeta, float* ds_drop, float* dbias, const unsigned* rng,
+                              unsigned site, float drop_p, int m, int e, cm_stream stream) {
+  if (!ds_drop && !dbias) return -22;
+  return ln_bwd_launch(sum_in, stats, gamma, dy, ds, dgamma, dbeta, ds_drop, dbias, rng, site, drop_p, m, e, stream);
 }
 
 static bool attn_ok(int b, int s, int e, int h) {

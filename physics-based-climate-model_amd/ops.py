@@ -844,12 +844,22 @@ def layernorm_fwd(x, resid, gamma, beta, eps=1e-5):
     return y, s, stats
 
 
-def layernorm_bwd(s, stats, gamma, dy, dgamma, dbeta):
+def layernorm_bwd(s, stats, gamma, dy, dgamma, dbeta, drop=None, dbias=None):
+    """ds = gradient wrt the LayerNorm's input.  With ``dbias`` (and optionally ``drop`` = (rng, site, p)) the launch also
+    produces the gradient wrt the sublayer output that was added through x + dropout(sublayer(x)) -- returned as a second
+    tensor (ds itself when there is no dropout) -- and accumulates its column sums into ``dbias``
+    (cm_layernorm_bwd_sublayer: one launch instead of three)."""
     m, e = s.shape
     ds = torch.empty_like(s)
-    check(lib.cm_layernorm_bwd(_p(s), _p(stats), _p(gamma), _p(_contig(dy)), _p(ds), _p(dgamma), _p(dbeta), m, e,
-                               _stream()), "layernorm_bwd")
-    return ds
+    if dbias is None and drop is None:
+        check(lib.cm_layernorm_bwd(_p(s), _p(stats), _p(gamma), _p(_contig(dy)), _p(ds), _p(dgamma), _p(dbeta), m, e,
+                                   _stream()), "layernorm_bwd")
+        return ds
+    rng, site, p = _drop_args(drop)
+    dd = torch.empty_like(s) if p > 0.0 else None
+    check(lib.cm_layernorm_bwd_sublayer(_p(s), _p(stats), _p(gamma), _p(_contig(dy)), _p(ds), _p(dgamma), _p(dbeta),
+                                        _p(dd), _p(dbias), rng, site, p, m, e, _stream()), "layernorm_bwd_sublayer")
+    return ds, (dd if dd is not None else ds)
 
 
 ATTENTION_MFMA = os.environ.get("CM_ATTENTION", "mfma") != "valu"     # CM_ATTENTION=valu: the fp32 VALU kernels everywhere

@@ -72,6 +72,16 @@ def test_layernorm(ops, m, e):
     dg = torch.zeros(e, device="cuda"); db = torch.zeros(e, device="cuda")
     ds = ops.layernorm_bwd(s, st, g.cuda(), dy.cuda(), dg, db)
     assert rel_l2(ds, xd.grad) < TOL and rel_l2(dg, gd.grad) < TOL and rel_l2(db, bd.grad) < TOL
+    # side outputs for the sublayer behind x + dropout(sublayer(x)): the masked gradient and its column sums (the bias
+    # gradient of the sublayer's last linear layer) == cm_dropout + cm_rowgroup_sum on ds
+    rng = torch.tensor([1234, 7], dtype=torch.int32, device="cuda")
+    for drop in (None, (rng, 5, 0.25)):
+        dg2 = torch.zeros(e, device="cuda"); db2 = torch.zeros(e, device="cuda"); dbias = torch.ones(e, device="cuda")
+        ds2, dd = ops.layernorm_bwd(s, st, g.cuda(), dy.cuda(), dg2, db2, drop=drop, dbias=dbias)
+        assert torch.equal(ds2, ds) and rel_l2(dg2, dg) < 1e-6 and rel_l2(db2, db) < 1e-6
+        want = ds if drop is None else ops.dropout(ds, drop)
+        assert torch.equal(dd, want)
+        assert rel_l2(dbias - 1.0, want.double().sum(0)) < 1e-5
 
 
 @pytest.mark.parametrize("b,s,e,h", [(2, 216, 256, 8), (3, 216, 32, 4), (1, 50, 64, 4), (2, 256, 64, 2)])
