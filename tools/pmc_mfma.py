@@ -50,9 +50,16 @@ def main():
         e = {"launches": int(a["launches"]), "avg_ns": a["ns"] / a["launches"],
              "mfma_busy_cycles_per_launch": a["SQ_VALU_MFMA_BUSY_CYCLES"] / a["launches"],
              "gui_active_cycles_per_launch": cyc / a["launches"]}
+        # Denominator: the kernel's duration x the NOMINAL shader clock (2.4 GHz, MI355X_MICROARCH.md) x 1024 SIMDs.  The
+        # GRBM_GUI_ACTIVE / 8 quotient reads high on dispatches shorter than ~0.3 ms (the guide's DVFS note; round 2's table
+        # showed an "effective clock" of 2.83 GHz, above the chip's maximum -- ADVICE r2), so it is kept only as a
+        # cross-check; at the true (lower) clock under load the busy fraction is somewhat HIGHER than this figure.
+        e["mfma_busy_frac"] = a["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * a["ns"] * 2.4)
+        e["clock_note"] = "busy cycles / (duration_ns x 2.4 GHz nominal x 1024 SIMDs): a lower bound of the busy fraction"
         if cyc > 0:
-            e["mfma_busy_frac"] = a["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc)
-            e["effective_clock_ghz"] = cyc / a["ns"]
+            e["mfma_busy_frac_gui_active"] = a["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc)
+            e["gui_active_clock_ghz"] = cyc / a["ns"]
+            e["gui_active_clock_plausible"] = bool(cyc / a["ns"] <= 2.4 * 1.02)
         for c in ("SQ_INSTS_VALU_MFMA_MOPS_F16", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_INSTS_VALU_MFMA_MOPS_F32"):
             if a.get(c):
                 e[c.lower() + "_per_launch"] = a[c] / a["launches"]
@@ -60,7 +67,7 @@ def main():
     json.dump(res, open(out, "w"), indent=1)
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]["mfma_busy_cycles_per_launch"] * kv[1]["launches"])[:8]:
         print(f"{k:34s} n={v['launches']:4d} avg {v['avg_ns'] / 1e3:7.1f} us  mfma busy {v.get('mfma_busy_frac', float('nan')):.3f}"
-              f"  clock {v.get('effective_clock_ghz', float('nan')):.2f} GHz")
+              f"  (GUI_ACTIVE clock {v.get('gui_active_clock_ghz', float('nan')):.2f} GHz)")
 
 
 if __name__ == "__main__":
