@@ -14,7 +14,8 @@ import torch  # noqa: F401  (device memory / streams come from torch anyway)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(_ROOT, "include", "climate_hip.h")
-LIB_PATH = os.path.join(_HERE, "libclimate_hip.so")
+# (CM_LIB_TAG: a second build of the same sources made with CM_BUILD_TAG, for A/B runs of a compiler option)
+LIB_PATH = os.path.join(_HERE, f"libclimate_hip{os.environ.get('CM_LIB_TAG', '')}.so")
 
 _CTYPES = {
     "int": ctypes.c_int,

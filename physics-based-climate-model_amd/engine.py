@@ -636,11 +636,9 @@ def convlstm_bwd(p: Params, pk, g: Params, gw: Params, ss, ctx: _LstmCtx, dbott:
     be = ctx.be
     ds4 = pk.conv("lstm.x/d", dA, cx, be_out=be[2])       # (first: publishes the per-sample magnitudes of dA)
 
-    def lstm_wgrads():
-        ops.wgrad3x3(ctx.s4, dA, gl, c_off=0, be_x=be[0], be_y=be[2])
-        if T > 1:   # hprev[:, 0] == 0 contributes nothing
-            ops.wgrad3x3(hprev.view(B * T, ch, h8, w8), dA, gl, c_off=cx, be_x=be[1], be_y=be[2])
-    ss.run(lstm_wgrads, ctx.s4, dA, hprev)
+    ss.run(lambda: ops.wgrad3x3(ctx.s4, dA, gl, c_off=0, be_x=be[0], be_y=be[2]), ctx.s4, dA)
+    if T > 1:   # hprev[:, 0] == 0 contributes nothing
+        ss.run(lambda: ops.wgrad3x3(hprev.view(B * T, ch, h8, w8), dA, gl, c_off=cx, be_x=be[1], be_y=be[2]), hprev, dA)
     ops.channel_sum(dA, g["convlstm.cell.conv.bias"])
     return ds4
 

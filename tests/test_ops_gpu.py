@@ -480,6 +480,68 @@ def test_block_tail_ties(ops):
     assert torch.equal(umax, fmap[:, 1])
 
 
+def _beside(victim, aggressor, replays=12):
+    """victim() on the capturing stream and aggressor() on a forked stream, recorded into one hipGraph: the outputs of every
+    replay against a solo run of the victim; returns the largest difference relative to the output's magnitude."""
+    solo = [t.clone() for t in victim()]
+    aggressor()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            aggressor()
+        out = victim()
+        main.wait_stream(side)
+    worst = 0.0
+    for _ in range(replays):
+        g.replay()
+        torch.cuda.synchronize()
+        worst = max([worst] + [((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item() for a, b in zip(out, solo)])
+    return worst
+
+
+def test_results_do_not_depend_on_a_coresident_mfma_kernel(ops):
+    """Regression for the round-3 finding (profiles/r03/coresidency/): with a weight-gradient MFMA kernel on
+    a second stream, cm_block_tail_bwd of the H/8 level and cm_gn_silu_bwd returned different values in lanes 48-63 of a wave
+    -- a packed-fp32 instruction form (v_pk_mul_f32 with the halves of src1 swapped) that the build now keeps out
+    (tools/isa_lint.py).  The same launches beside the same kernel must reproduce their solo results."""
+    n, c, h, w = 96, 256, 6, 9
+    cr = c // 8
+    torch.manual_seed(0)
+    y2 = torch.randn(n, c, h, w, device="cuda")
+    gamma = torch.rand(c, device="cuda") + 0.5
+    beta = torch.randn(c, device="cuda") * 0.1
+    w1 = torch.randn(cr, c, 1, 1, device="cuda") * 0.3
+    w2 = torch.randn(c, cr, 1, 1, device="cuda") * 0.3
+    w7 = torch.randn(1, 2, 7, 7, device="cuda") * 0.1
+    dout = torch.randn(n, c, h, w, device="cuda")
+    y2, st, pooled, z, s, fmap, gate = ops.block_tail_fwd(y2, gamma, beta, w1, w2, w7, pool_out=False)[:7]
+    dw7 = torch.zeros_like(w7)
+    dg = torch.zeros(c, device="cuda"); db = torch.zeros(c, device="cuda")
+
+    def tail_bwd():
+        dmap, (umax, cnt), dpool, (dsig, dz) = ops.block_tail_bwd(dout, y2, st, gamma, beta, s, z, gate, fmap, w1, w2, w7, dw7)
+        return [dmap, umax, cnt, dpool, dsig, dz]
+
+    def gn_bwd():
+        return [ops.gn_silu_bwd(y2, gamma, beta, st, dout, dg, db)]
+
+    # the aggressor of the original case: the ConvLSTM's h-part weight gradient (128 -> 512 channels at 6x9), configuration 0
+    hp = torch.tanh(torch.randn(n, 128, h, w, device="cuda"))
+    dA = torch.randn(n, 512, h, w, device="cuda")
+    gl = torch.zeros(512, 9, 384, device="cuda")
+    bex, bey = ops.SampleExponents.measure(hp), ops.SampleExponents.measure(dA)
+
+    def wgrad():
+        ops.wgrad3x3(hp, dA, gl, c_off=256, be_x=bex, be_y=bey, config=ops.H3_BASE + 0 + (4 << 8))
+
+    assert _beside(tail_bwd, wgrad) == 0.0           # (deterministic launch: bit for bit; the defect gave 0.1 - 0.3)
+    assert _beside(gn_bwd, wgrad) < 5e-6             # (group sums by atomics: one or two ulps from run to run on its own)
+
+
 def test_conv7_bwd_many_workgroups(ops):
     """conv7 backward at the benchmark width (1152-row partial table + fold), accumulating over repeated launches."""
     torch.manual_seed(4)
