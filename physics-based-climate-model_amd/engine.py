@@ -488,14 +488,15 @@ class _SideStream:
         self.keep.clear()
 
 
-# Both side-stream overlaps are OFF and cannot be switched on from the environment (they are module attributes that only
-# a test or a probe sets, e.g. tests/test_model_gpu.py::test_side_stream_overlap_eager_three_steps): they measure 0-4 %
-# either way on config 2, and round 1 saw non-finite values in EAGER mode with the weight-gradient overlap on -- the
-# gate backward compared a2*s with the channel maximum the forward had STORED, once received a stale SE scale `s`,
-# found no channel equal to the stored maximum, and divided by a tie count of 0.  The stale read was never reproduced
-# (tools/overlap_probe.py: 0 mismatches in 56 launches) and the gate backward no longer depends on bitwise agreement with
-# another launch (it derives maximum AND tie count from the values it reads itself, count >= 1 by construction), but
-# until the read is explained the schedule stays out of reach of a production run.
+# Both side-stream overlaps are OFF and cannot be switched on from the environment (module attributes that only a test or a
+# probe sets, e.g. tests/test_model_gpu.py::test_side_stream_overlap_three_steps): they measure 0 to -32 % on config 2
+# (a third and fourth stream oversubscribe the hardware queues; profiles/r03/ab_bench.txt).
+# History: round 1 saw non-finite values in EAGER mode with the weight-gradient overlap on, rounds 2-3 gradients 1e-4..1e-3
+# away from the serial schedule.  Root cause (round 3, profiles/r03/coresidency/): not a missing dependency -- with the
+# ConvLSTM weight gradient on the side stream, cm_block_tail_bwd / cm_gn_silu_bwd ran beside an MFMA kernel, and a
+# packed-fp32 instruction form the compiler had emitted in them (v_pk_mul_f32 with the halves of src1 swapped) returns wrong
+# values in lanes 48-63 of a wave in that situation.  The form is kept out of the library now (build.py, tools/isa_lint.py)
+# and both ways of issuing the schedule agree with the serial one to 1e-6.
 OVERLAP_WGRAD = False
 # Under graph capture a stream that ENTERS the capture from a non-origin stream (a fork inside a forked stream: the child of
 # the second micro-batch's stream) crashes hipStreamEndCapture on this runtime; children that entered as first-level forks of
