@@ -383,6 +383,13 @@ int cm_gemm_h3(const float* a, long long lda, int trans_a, const float* b, long 
                long long ldc, const float* bias, const float* resid, long long ldr, int res_rows, const float* mask,
                long long ldm, float mask_scale, int relu, const unsigned* rng, unsigned site, float drop_p, int m, int n,
                int k, int ksplit, int tile, cm_stream stream);
+/* Weight and bias gradient of a linear layer in one launch (nn.Linear inside nn.TransformerEncoderLayer and the im2col
+ * convolutions, src/cnn_transformer.py:9-13,26-33): dw[n_out][k_in] += dy^T x over `tokens` rows (split-K, atomics, as
+ * cm_gemm_h3 with trans_a = trans_b = 1) and, when dbias != null, dbias[n_out] += column sums of dy -- the workgroups of
+ * the first column of tiles add up the dy tiles they stage anyway (replaces a cm_rowgroup_sum launch).  ksplit = 1
+ * STORES dw (as cm_gemm_h3 does); dbias always accumulates.                                                            */
+int cm_gemm_h3_wgrad(const float* dy, long long ld_dy, const float* x, long long ldx, float* dw, long long ld_dw,
+                     float* dbias, int n_out, int k_in, int tokens, int ksplit, int tile, cm_stream stream);
 /* post-norm residual LayerNorm, eps as given (nn.LayerNorm default 1e-5): sum_out = x + resid (nullable resid; kept for
  * the backward), y = LN(sum_out) * gamma + beta, stats[m][2] = {mean, rstd}.  e <= 1024.                          */
 int cm_layernorm_fwd(const float* x, const float* resid, const float* gamma, const float* beta, float* sum_out, float* y,

@@ -103,13 +103,14 @@ def _add_pos(t0: Tensor, pos: Tensor, S: int) -> Tensor:
     return out
 
 
-def _wgrad(dy: Tensor, x: Tensor, dw: Tensor, n_out: int, k_in: int, tokens: int):
-    """dw [n_out, k_in] += dy^T x  (dy [tokens, n_out], x [tokens, >= k_in]): split-K GEMM over the tokens."""
+def _wgrad(dy: Tensor, x: Tensor, dw: Tensor, n_out: int, k_in: int, tokens: int, dbias: Tensor = None):
+    """dw [n_out, k_in] += dy^T x  (dy [tokens, n_out], x [tokens, >= k_in]): split-K GEMM over the tokens; with ``dbias``
+    the same launch adds the column sums of dy into it (the layer's bias gradient)."""
     # reduction split: enough workgroups to fill the chip (~384 of 128 x 128 tiles), at least 256 tokens each
     # (tools/gemm_bench.py: 768 x 256 is fastest at 32 splits, 256 x 256 at 54)
     tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)
     ks = max(1, min(64, tokens // 256, max(8, 384 // tiles)))
-    ops.gemm(dy, x, n_out, k_in, tokens, trans_a=True, trans_b=True, out=dw.view(n_out, k_in), ksplit=ks)
+    ops.gemm_wgrad(dy, x, dw.view(n_out, k_in), n_out, k_in, tokens, ks, dbias=dbias)
 
 
 def backward(p: Dict[str, Tensor], g: Dict[str, Tensor], sv, n_heads: int, dpred=None, dd_head=None, need_dx=False):
@@ -140,25 +141,21 @@ def backward(p: Dict[str, Tensor], g: Dict[str, Tensor], sv, n_heads: int, dpred
         _wgrad(dm2, h1, g[q + "linear2.weight"], E, mlp, M)
         # through linear2, the MLP dropout and the ReLU: h1 is the DROPPED activation, so h1 > 0 <=> kept and positive
         dh1 = ops.gemm(dm2, p[q + "linear2.weight"], M, mlp, E, trans_b=True, mask=h1, mask_scale=keep_scale)
-        ops.rowgroup_sum(dh1, g[q + "linear1.bias"].view(1, mlp))
-        _wgrad(dh1, t1, g[q + "linear1.weight"], mlp, E, M)
+        _wgrad(dh1, t1, g[q + "linear1.weight"], mlp, E, M, dbias=g[q + "linear1.bias"])
         dt1 = ops.gemm(dh1, p[q + "linear1.weight"], M, E, mlp, trans_b=True, resid=ds2, res_rows=M)   # + residual branch
         ds1, da = ops.layernorm_bwd(s1, st1, p[q + "norm1.weight"], dt1, g[q + "norm1.weight"], g[q + "norm1.bias"],
                                     drop=dr[1], dbias=g[q + "self_attn.out_proj.bias"])
         _wgrad(da, o, g[q + "self_attn.out_proj.weight"], E, E, M)
         d_o = ops.gemm(da, p[q + "self_attn.out_proj.weight"], M, E, E, trans_b=True)
         dqkv = ops.attention_bwd(qkv, P, d_o, B, S, E, n_heads, drop=dr[0], o=o)
-        ops.rowgroup_sum(dqkv, g[q + "self_attn.in_proj_bias"].view(1, 3 * E))
-        _wgrad(dqkv, t_in, g[q + "self_attn.in_proj_weight"], 3 * E, E, M)
+        _wgrad(dqkv, t_in, g[q + "self_attn.in_proj_weight"], 3 * E, E, M, dbias=g[q + "self_attn.in_proj_bias"])
         dt = ops.gemm(dqkv, p[q + "self_attn.in_proj_weight"], M, E, 3 * E, trans_b=True, resid=ds1, res_rows=M)
     ops.rowgroup_sum(dt, g["pos_embedding"].view(S, E), period=S)
     dt0 = ops.relu_mask_(dt, sv.t0)
-    ops.rowgroup_sum(dt0, g["encoder.2.bias"].view(1, E))
-    _wgrad(dt0, sv.col2, g["encoder.2.weight"], E, E2 * 9, M)
+    _wgrad(dt0, sv.col2, g["encoder.2.weight"], E, E2 * 9, M, dbias=g["encoder.2.bias"])
     dcol2 = ops.gemm(dt0, p["encoder.2.weight"].view(E, E2 * 9), M, E2 * 9, E, trans_b=True)
     dy1 = ops.relu_mask_(ops.col2im_s2(dcol2, B, E2, H // 2, W // 2), sv.y1)
-    ops.rowgroup_sum(dy1, g["encoder.0.bias"].view(1, E2))
-    _wgrad(dy1, sv.col1, g["encoder.0.weight"], E2, Cin * 9, M1)
+    _wgrad(dy1, sv.col1, g["encoder.0.weight"], E2, Cin * 9, M1, dbias=g["encoder.0.bias"])
     if not need_dx:
         return None
     dcol1 = ops.gemm(dy1, p["encoder.0.weight"].view(E2, Cin * 9), M1, Cin * 9, E2, trans_b=True)

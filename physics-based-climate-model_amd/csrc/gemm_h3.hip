@@ -35,6 +35,7 @@ struct GemmArgs {
   unsigned site;
   float drop_p;
   float mask_scale;       // factor on the elements the mask keeps (ReLU backward through a DROPPED activation: 1/(1-p))
+  float* a_rowsum;        // [M] or null (transposed A only): += sum over k of op(A)[m][k] -- with A = dY^T the bias gradient
 };
 
 constexpr int GBM = 128, GBN = 128, GBK = 32;
@@ -182,6 +183,8 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
   if (tid < 4) smax[tid >> 1][tid & 1] = 0u;
   __syncthreads();
   float va[16], vb[16];
+  float rsum[2] = {0.f, 0.f};
+  const bool sum_rows = TA && a.a_rowsum != nullptr && blockIdx.x == 0;     // (the first column of tiles does it once)
   unsigned bea = 0, beb = 0;                 // biased exponents of the running maxima
   auto post = [&](int par) {
     float ma = 0.f, mb = 0.f;
@@ -215,6 +218,12 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
       bea = na; beb = nb;
     }
     const float sa = __uint_as_float((267u - max(bea, 13u)) << 23), sb = __uint_as_float((267u - max(beb, 13u)) << 23);
+    if constexpr (TA) {                      // row sums of op(A) ride along: this thread's rows are fixed (lane, lane + 64)
+      if (sum_rows) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { rsum[0] += va[j]; rsum[1] += va[8 + j]; }
+      }
+    }
     if constexpr (BM == 128) gemm_store_tile<TA>(Al, tid, va, sa);
     else gemm_store_tile64<TA>(Al, tid, va, sa);
     if constexpr (BN == 128) gemm_store_tile<TB>(Bl, tid, vb, sb);
@@ -251,6 +260,16 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
     __syncthreads();
   }
 
+  if constexpr (TA) {
+    if (sum_rows) {                          // 4 waves hold the 4 k octets of every row: combine through LDS, one atomic per row
+      float* red = reinterpret_cast<float*>(Al);          // (free after the loop's last barrier)
+      red[wave * 128 + lane] = rsum[0];
+      red[wave * 128 + 64 + lane] = rsum[1];
+      __syncthreads();
+      if (tid < BM && m0 + tid < a.M)
+        unsafeAtomicAdd(a.a_rowsum + m0 + tid, (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]));
+    }
+  }
   // ---- epilogue: undo the scales, bias / residual / ReLU / mask, store (or accumulate for split K) ----
   const float ia = bea <= 13u ? 0.f : __uint_as_float((bea - 13u) << 23);
   const float ib = beb <= 13u ? 0.f : __uint_as_float((beb - 13u) << 23);
@@ -284,10 +303,29 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
 
 extern "C" {
 
+static int gemm_h3_launch(const float* a, long long lda, int trans_a, const float* b, long long ldb, int trans_b, float* c,
+                          long long ldc, const float* bias, const float* resid, long long ldr, int res_rows,
+                          const float* mask, long long ldm, float mask_scale, int relu, const unsigned* rng, unsigned site,
+                          float drop_p, int m, int n, int k, int ksplit, int tile, float* a_rowsum, cm_stream stream);
+
 int cm_gemm_h3(const float* a, long long lda, int trans_a, const float* b, long long ldb, int trans_b, float* c,
                long long ldc, const float* bias, const float* resid, long long ldr, int res_rows, const float* mask,
                long long ldm, float mask_scale, int relu, const unsigned* rng, unsigned site, float drop_p, int m, int n,
                int k, int ksplit, int tile, cm_stream stream) {
+  return gemm_h3_launch(a, lda, trans_a, b, ldb, trans_b, c, ldc, bias, resid, ldr, res_rows, mask, ldm, mask_scale, relu,
+                        rng, site, drop_p, m, n, k, ksplit, tile, nullptr, stream);
+}
+
+int cm_gemm_h3_wgrad(const float* dy, long long ld_dy, const float* x, long long ldx, float* dw, long long ld_dw,
+                     float* dbias, int n_out, int k_in, int tokens, int ksplit, int tile, cm_stream stream) {
+  return gemm_h3_launch(dy, ld_dy, 1, x, ldx, 1, dw, ld_dw, nullptr, nullptr, 0, 0, nullptr, 0, 1.f, 0, nullptr, 0, 0.f,
+                        n_out, k_in, tokens, ksplit, tile, dbias, stream);
+}
+
+static int gemm_h3_launch(const float* a, long long lda, int trans_a, const float* b, long long ldb, int trans_b, float* c,
+                          long long ldc, const float* bias, const float* resid, long long ldr, int res_rows,
+                          const float* mask, long long ldm, float mask_scale, int relu, const unsigned* rng, unsigned site,
+                          float drop_p, int m, int n, int k, int ksplit, int tile, float* a_rowsum, cm_stream stream) {
   if (m <= 0 || n <= 0 || k <= 0 || !a || !b || !c || lda <= 0 || ldb <= 0 || ldc < n) return -22;
   if (ksplit < 1) ksplit = 1;
   if (ksplit > 1 && (resid || mask || relu || (rng && drop_p > 0.f))) return -22;   // split K accumulates raw sums
@@ -299,6 +337,7 @@ int cm_gemm_h3(const float* a, long long lda, int trans_a, const float* b, long 
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.ldm = ldm;
   g.M = m; g.N = n; g.K = k; g.res_rows = res_rows > 0 ? res_rows : m; g.relu = relu;
   g.rng = drop_p > 0.f ? rng : nullptr; g.site = site; g.drop_p = drop_p; g.mask_scale = mask_scale;
+  g.a_rowsum = a_rowsum;
   const int nstage = cdiv(k, GBK);
   g.ksplit = ksplit > nstage ? nstage : ksplit;
   hipStream_t st = (hipStream_t)stream;

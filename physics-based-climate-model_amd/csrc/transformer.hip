@@ -68,34 +68,61 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ s
   float ag[VPL], ab[VPL], abias[VPL];
 #pragma unroll
   for (int i = 0; i < VPL; ++i) { ag[i] = 0.f; ab[i] = 0.f; abias[i] = 0.f; }
-  const int r0 = blockIdx.x * rows_per_wg;
-  for (int row = r0 + wv; row < min(M, r0 + rows_per_wg); row += 4) {
-    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
-    float xh[VPL], g[VPL], s1 = 0.f, s2 = 0.f;
+  const int r0 = blockIdx.x * rows_per_wg, rend = min(M, r0 + rows_per_wg);
+  // RB rows of a wave are in flight at once (their loads are issued before the first reduction): with one row at a time a
+  // wave waited out a full load latency per row, and the launch has too few waves per CU to hide it behind others
+  constexpr int RB = VPL <= 4 ? 4 : 2;
+  for (int rowb = r0 + wv; rowb < rend; rowb += 4 * RB) {
+    float xh[RB][VPL], g[RB][VPL], dv[RB][VPL], mean[RB], rstd[RB], s1[RB], s2[RB];
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-      const int c = lane + 64 * i;
-      const bool ok = c < E;
-      const float d = ok ? dy[(long long)row * E + c] : 0.f;
-      xh[i] = ok ? (s[(long long)row * E + c] - mean) * rstd : 0.f;
-      g[i] = ok ? d * gamma[c] : 0.f;
-      s1 += g[i];
-      s2 += g[i] * xh[i];
-      ag[i] += d * xh[i];
-      ab[i] += d;
+    for (int b = 0; b < RB; ++b) {
+      const int row = rowb + 4 * b;
+      const bool rok = row < rend;
+      mean[b] = rok ? stats[2 * row] : 0.f;
+      rstd[b] = rok ? stats[2 * row + 1] : 0.f;
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) {
+        const int c = lane + 64 * i;
+        const bool ok = rok && c < E;
+        dv[b][i] = ok ? dy[(long long)row * E + c] : 0.f;
+        xh[b][i] = ok ? s[(long long)row * E + c] : 0.f;
+      }
     }
-    s1 = wave_sum(s1) / (float)E;
-    s2 = wave_sum(s2) / (float)E;
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-      const int c = lane + 64 * i;
-      if (c < E) {
-        const float d = rstd * (g[i] - s1 - xh[i] * s2);
-        ds[(long long)row * E + c] = d;
-        if (ds_drop || dbias) {
-          const float dd = drop.thresh ? d * cm_drop_mul(drop, (unsigned)row * (unsigned)E + (unsigned)c) : d;
-          if (ds_drop) ds_drop[(long long)row * E + c] = dd;
-          abias[i] += dd;
+    for (int b = 0; b < RB; ++b) {
+      s1[b] = 0.f; s2[b] = 0.f;
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) {
+        const int c = lane + 64 * i;
+        const bool ok = rowb + 4 * b < rend && c < E;
+        xh[b][i] = ok ? (xh[b][i] - mean[b]) * rstd[b] : 0.f;
+        g[b][i] = ok ? dv[b][i] * gamma[c] : 0.f;
+        s1[b] += g[b][i];
+        s2[b] += g[b][i] * xh[b][i];
+        ag[i] += dv[b][i] * xh[b][i];
+        ab[i] += dv[b][i];
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+      s1[b] = wave_sum(s1[b]) / (float)E;
+      s2[b] = wave_sum(s2[b]) / (float)E;
+    }
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+      const int row = rowb + 4 * b;
+      if (row >= rend) continue;
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) {
+        const int c = lane + 64 * i;
+        if (c < E) {
+          const float d = rstd[b] * (g[b][i] - s1[b] - xh[b][i] * s2[b]);
+          ds[(long long)row * E + c] = d;
+          if (ds_drop || dbias) {
+            const float dd = drop.thresh ? d * cm_drop_mul(drop, (unsigned)row * (unsigned)E + (unsigned)c) : d;
+            if (ds_drop) ds_drop[(long long)row * E + c] = dd;
+            abias[i] += dd;
+          }
         }
       }
     }

@@ -834,6 +834,14 @@ def gemm(a, b, m, n, k, trans_a=False, trans_b=False, bias=None, resid=None, res
     return out
 
 
+def gemm_wgrad(dy, x, dw, n_out, k_in, tokens, ksplit, dbias=None, tile=0):
+    """dw [n_out, k_in] += dy^T x (dy [tokens, n_out], x [tokens, >= k_in]) and, with ``dbias``, dbias [n_out] += the column
+    sums of dy in the same launch (cm_gemm_h3_wgrad)."""
+    check(lib.cm_gemm_h3_wgrad(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), dw.stride(0), _p(dbias), n_out, k_in,
+                               tokens, ksplit, int(tile), _stream()), "gemm_h3_wgrad")
+    return dw
+
+
 def layernorm_fwd(x, resid, gamma, beta, eps=1e-5):
     m, e = x.shape
     s = torch.empty_like(x)

@@ -86,8 +86,18 @@ def _gemm_bytes(a):
     return 4.0 * (m * k + n * k + m * n)
 
 
+def _gemm_wgrad_flops(a):  # cm_gemm_h3_wgrad(dy, ld_dy, x, ldx, dw, ld_dw, dbias, n_out, k_in, tokens, ksplit, tile, stream)
+    return 2.0 * a[7] * a[8] * a[9]
+
+
+def _gemm_wgrad_bytes(a):
+    n, k, t = a[7], a[8], a[9]
+    return 4.0 * (t * n + t * k + n * k)
+
+
 MODELS = {
     "cm_gemm_h3": (_gemm_flops, _gemm_bytes),           # ALGORITHMIC flops (x3 are executed)
+    "cm_gemm_h3_wgrad": (_gemm_wgrad_flops, _gemm_wgrad_bytes),
     "cm_conv3x3": (_conv_flops, _conv_bytes),
     "cm_conv3x3_split": (_conv_flops, _conv_bytes),     # same argument positions; ALGORITHMIC flops (x6 are executed)
     "cm_conv3x3_h3": (_conv_h3_flops, _conv_h3_bytes),  # ALGORITHMIC flops (x3 are executed)

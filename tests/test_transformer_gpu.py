@@ -49,6 +49,25 @@ def test_gemm_fp16x3_all_layouts(ops, m, n, k, ta, tb, tile):
         assert rel_l2(acc, 2 * ref) < 2e-6, ks
 
 
+@pytest.mark.parametrize("tokens,n_out,k_in", [(6912, 768, 256), (500, 70, 45), (1000, 129, 33), (4096, 256, 1152)])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+def test_gemm_wgrad_with_bias_gradient(ops, tokens, n_out, k_in, tile):
+    """cm_gemm_h3_wgrad: dw += dy^T x and dbias += column sums of dy in one launch (nn.Linear's two parameter gradients),
+    accumulating over repeated launches and for every reduction split."""
+    dy = rnd(tokens, n_out, seed=21); x = rnd(tokens, k_in, seed=22)
+    want_w = dy.double().t() @ x.double()
+    want_b = dy.double().sum(0)
+    for ks in (1, 7, 32):
+        dw = torch.zeros(n_out, k_in, device="cuda"); dbias = torch.zeros(n_out, device="cuda")
+        ops.gemm_wgrad(dy.cuda(), x.cuda(), dw, n_out, k_in, tokens, ks, dbias=dbias, tile=tile)
+        ops.gemm_wgrad(dy.cuda(), x.cuda(), dw, n_out, k_in, tokens, ks, dbias=dbias, tile=tile)
+        assert rel_l2(dw, (2 if ks > 1 else 1) * want_w) < 2e-6, ks          # (ksplit = 1 STORES dw, as cm_gemm_h3 does)
+        assert rel_l2(dbias, 2 * want_b) < 2e-6, ks                          # (the side output always accumulates)
+        dw2 = torch.zeros(n_out, k_in, device="cuda")
+        ops.gemm_wgrad(dy.cuda(), x.cuda(), dw2, n_out, k_in, tokens, ks, tile=tile)         # without the side output
+        assert rel_l2(dw2, want_w) < 2e-6, ks
+
+
 @pytest.mark.parametrize("amag,bmag", [(1e-9, 1.0), (3e7, 1e-6), (1e-18, 1e-14), (1e12, 1e9)])
 def test_gemm_fp16x3_any_magnitude(ops, amag, bmag):
     m, n, k = 200, 150, 300
