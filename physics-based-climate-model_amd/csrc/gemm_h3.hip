@@ -129,7 +129,7 @@ __device__ __forceinline__ void gemm_load_tile64(const float* __restrict__ P, lo
   for (int j = 8; j < 16; ++j) v[j] = 0.f;
 }
 
-template <bool TRANS>
+template <bool TRANS, int PITCH = 128>
 __device__ __forceinline__ void gemm_store_tile64(gu32x4* __restrict__ L, int tid, const float (&v)[16], float sc) {
   const int row = TRANS ? (tid & 63) : (tid >> 2), oct = TRANS ? (tid >> 6) : (tid & 3);
   gu32x4 ph, pl;
@@ -139,8 +139,8 @@ __device__ __forceinline__ void gemm_store_tile64(gu32x4* __restrict__ L, int ti
     split2_pair_f16(v[2 * q] * sc, v[2 * q + 1] * sc, a_, b_);
     ph[q] = a_; pl[q] = b_;
   }
-  L[(0 * 4 + oct) * 128 + row] = ph;
-  L[(1 * 4 + oct) * 128 + row] = pl;
+  L[(0 * 4 + oct) * PITCH + row] = ph;
+  L[(1 * 4 + oct) * PITCH + row] = pl;
 }
 
 // BN = 128: 2 x 2 waves of 64 x 64;  BN = 64: 4 x 1 waves of 32 x 64 (twice the workgroups for the narrow GEMMs --
@@ -148,18 +148,23 @@ __device__ __forceinline__ void gemm_store_tile64(gu32x4* __restrict__ L, int ti
 // staging arithmetic behind).
 // BM = BN = 64: 2 x 2 waves of 32 x 32 (four times the workgroups: for the GEMMs whose 128 x 64 tiling still leaves the
 // chip under ~4 workgroups per CU).
-template <bool TA, bool TB, int BN = 128, int BM = 128>
+template <bool TA, bool TB, int BN = 128, int BM = 128, int NHALF = 2>
 __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
   static_assert(BM == 128 || (BM == 64 && BN == 64), "tile shapes: 128x128, 128x64, 64x64");
   constexpr int TI = (BM == 128 && BN == 128) ? 2 : 1, TJ = BM == 64 ? 1 : 2;
-  __shared__ gu32x4 Al[2 * 4 * 128], Bl[2 * 4 * 128];   // [piece][k octet][row / column]
+  constexpr int NH = (BM == 64 && BN == 64) ? NHALF : 1;      // 32-deep images per stage (64 x 64 tiles only)
+  constexpr int LP = NH * 64 > 128 ? NH * 64 : 128;           // row pitch of the LDS images
+  __shared__ gu32x4 Al[2 * 4 * LP], Bl[2 * 4 * LP];           // [piece][k octet][row / column]
   __shared__ unsigned smax[2][2];                       // [stage parity][A, B] posted maxima
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
   const int wr_off = BM == 64 ? (wave >> 1) * 32 : (BN == 128 ? (wave >> 1) * 64 : wave * 32);   // this wave's rows ..
   const int wc_off = BM == 64 ? (wave & 1) * 32 : (BN == 128 ? (wave & 1) * 64 : 0);            // .. and columns in the tile
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int nstage = (a.K + GBK - 1) / GBK;
+  // 64 x 64 tiles stage 64 of K per barrier pair: two 32-deep images side by side (rows 0-63 and 64-127 of the LDS arrays,
+  // which are sized for the 128-row tiles), one maximum reduction and one rescale check for both
+  constexpr int SK = GBK * NH;
+  const int nstage = (a.K + SK - 1) / SK;
   const int sps = (nstage + a.ksplit - 1) / a.ksplit;
   const int s_begin = blockIdx.z * sps, s_end = min(nstage, s_begin + sps);
   if (s_begin >= s_end) return;
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
 
   if (tid < 4) smax[tid >> 1][tid & 1] = 0u;
   __syncthreads();
-  float va[16], vb[16];
+  float va[16], vb[16], va2[NH > 1 ? NH - 1 : 1][16], vb2[NH > 1 ? NH - 1 : 1][16];
   float rsum[2] = {0.f, 0.f};
   const bool sum_rows = TA && a.a_rowsum != nullptr && blockIdx.x == 0;     // (the first column of tiles does it once)
   unsigned bea = 0, beb = 0;                 // biased exponents of the running maxima
@@ -190,6 +195,12 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
     float ma = 0.f, mb = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { ma = fmaxf(ma, fabsf(va[i])); mb = fmaxf(mb, fabsf(vb[i])); }
+    if constexpr (NH > 1) {
+#pragma unroll
+      for (int h = 0; h < NH - 1; ++h)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { ma = fmaxf(ma, fabsf(va2[h][i])); mb = fmaxf(mb, fabsf(vb2[h][i])); }
+    }
     ma = wave_max_nonneg(ma);
     mb = wave_max_nonneg(mb);
     if (lane == 0) {
@@ -197,8 +208,15 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
       atomicMax(&smax[par][1], __float_as_uint(mb));
     }
   };
-  load_a(s_begin * GBK, va);
-  load_b(s_begin * GBK, vb);
+  load_a(s_begin * SK, va);
+  load_b(s_begin * SK, vb);
+  if constexpr (NH > 1) {
+#pragma unroll
+    for (int h = 0; h < NH - 1; ++h) {
+      load_a(s_begin * SK + (h + 1) * GBK, va2[h]);
+      load_b(s_begin * SK + (h + 1) * GBK, vb2[h]);
+    }
+  }
   post(0);
   __syncthreads();
   for (int s = s_begin; s < s_end; ++s) {
@@ -222,30 +240,50 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
       if (sum_rows) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { rsum[0] += va[j]; rsum[1] += va[8 + j]; }
+        if constexpr (NH > 1) {
+#pragma unroll
+          for (int h = 0; h < NH - 1; ++h)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rsum[0] += va2[h][j];
+        }
       }
     }
     if constexpr (BM == 128) gemm_store_tile<TA>(Al, tid, va, sa);
-    else gemm_store_tile64<TA>(Al, tid, va, sa);
+    else gemm_store_tile64<TA, LP>(Al, tid, va, sa);
     if constexpr (BN == 128) gemm_store_tile<TB>(Bl, tid, vb, sb);
-    else gemm_store_tile64<TB>(Bl, tid, vb, sb);
+    else gemm_store_tile64<TB, LP>(Bl, tid, vb, sb);
+    if constexpr (NH > 1) {
+#pragma unroll
+      for (int h = 0; h < NH - 1; ++h) {
+        gemm_store_tile64<TA, LP>(Al + 64 * (h + 1), tid, va2[h], sa);
+        gemm_store_tile64<TB, LP>(Bl + 64 * (h + 1), tid, vb2[h], sb);
+      }
+    }
     __syncthreads();
     if (tid < 2) smax[par][tid] = 0u;
     if (s + 1 < s_end) {
-      load_a((s + 1) * GBK, va);
-      load_b((s + 1) * GBK, vb);
+      load_a((s + 1) * SK, va);
+      load_b((s + 1) * SK, vb);
+      if constexpr (NH > 1) {
+#pragma unroll
+        for (int h = 0; h < NH - 1; ++h) {
+          load_a((s + 1) * SK + (h + 1) * GBK, va2[h]);
+          load_b((s + 1) * SK + (h + 1) * GBK, vb2[h]);
+        }
+      }
     }
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {         // two 16-deep MFMA k-steps per stage; the lane half picks the octet
-      const int oct = ks * 2 + half;
+    for (int ks = 0; ks < 2 * NH; ++ks) {    // 16-deep MFMA k-steps of the stage; the lane half picks the octet
+      const int oct = (ks & 1) * 2 + half, hb = (ks >> 1) * 64;
       f16x8 af[2][TI], bf[2][TJ];            // [piece][tile]
 #pragma unroll
       for (int pc = 0; pc < 2; ++pc) {
 #pragma unroll
         for (int t = 0; t < TI; ++t)
-          af[pc][t] = __builtin_bit_cast(f16x8, Al[(pc * 4 + oct) * 128 + wr_off + t * 32 + l31]);
+          af[pc][t] = __builtin_bit_cast(f16x8, Al[(pc * 4 + oct) * LP + hb + wr_off + t * 32 + l31]);
 #pragma unroll
         for (int t = 0; t < TJ; ++t)
-          bf[pc][t] = __builtin_bit_cast(f16x8, Bl[(pc * 4 + oct) * 128 + wc_off + t * 32 + l31]);
+          bf[pc][t] = __builtin_bit_cast(f16x8, Bl[(pc * 4 + oct) * LP + hb + wc_off + t * 32 + l31]);
       }
 #pragma unroll
       for (int i = 0; i < TI; ++i)
@@ -338,7 +376,7 @@ static int gemm_h3_launch(const float* a, long long lda, int trans_a, const floa
   g.M = m; g.N = n; g.K = k; g.res_rows = res_rows > 0 ? res_rows : m; g.relu = relu;
   g.rng = drop_p > 0.f ? rng : nullptr; g.site = site; g.drop_p = drop_p; g.mask_scale = mask_scale;
   g.a_rowsum = a_rowsum;
-  const int nstage = cdiv(k, GBK);
+  const int nstage = cdiv(k, GBK);              // (the 64 x 64 kernel counts 64-deep stages itself: empty shares return)
   g.ksplit = ksplit > nstage ? nstage : ksplit;
   hipStream_t st = (hipStream_t)stream;
   // narrow tiles when 128 x 128 tiles would give fewer than ~4 workgroups per CU (CM_GEMM_NARROW: 512 -> 9665, 1024 -> 9765, always -> 9755, never -> 8749 samples/s at config 4)
@@ -352,10 +390,17 @@ static int gemm_h3_launch(const float* a, long long lda, int trans_a, const floa
   const bool want_small = tile == 3 || (tile == 0 && (long long)cdiv(n, 64) * cdiv(m, GBM) * g.ksplit < small_below);
   if (want_small) {      // 64 x 64 tiles
     const dim3 grid(cdiv(n, 64), cdiv(m, 64), g.ksplit);
-    if (!trans_a && !trans_b) gemm_h3_kernel<false, false, 64, 64><<<grid, 256, 0, st>>>(g);
-    else if (!trans_a && trans_b) gemm_h3_kernel<false, true, 64, 64><<<grid, 256, 0, st>>>(g);
-    else if (trans_a && trans_b) gemm_h3_kernel<true, true, 64, 64><<<grid, 256, 0, st>>>(g);
-    else gemm_h3_kernel<true, false, 64, 64><<<grid, 256, 0, st>>>(g);
+    // 32-deep images per stage: CM_GEMM_NH = 1 | 2 | 4 (default 2: 64 of K per barrier pair)
+    static const int nh = getenv("CM_GEMM_NH") ? atoi(getenv("CM_GEMM_NH")) : 2;
+#define CM_G64(NHV)                                                                                    \
+    do {                                                                                               \
+      if (!trans_a && !trans_b) gemm_h3_kernel<false, false, 64, 64, NHV><<<grid, 256, 0, st>>>(g);     \
+      else if (!trans_a && trans_b) gemm_h3_kernel<false, true, 64, 64, NHV><<<grid, 256, 0, st>>>(g);  \
+      else if (trans_a && trans_b) gemm_h3_kernel<true, true, 64, 64, NHV><<<grid, 256, 0, st>>>(g);    \
+      else gemm_h3_kernel<true, false, 64, 64, NHV><<<grid, 256, 0, st>>>(g);                           \
+    } while (0)
+    if (nh == 1) CM_G64(1); else if (nh == 4) CM_G64(4); else CM_G64(2);
+#undef CM_G64
     CM_CHECK_LAUNCH();
     return 0;
   }
