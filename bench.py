@@ -279,11 +279,11 @@ def bench_cnn_transformer(args):
                              "ms_per_step": round(d["ms"] / args.profile_steps, 4)}
             if d["flops"]:
                 kernels[name]["tflops"] = round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2)
-        fam = [d for n_, d in kt.summary().items() if n_.startswith("cm_gemm_h3")]      # cm_gemm_h3 + cm_gemm_h3_wgrad
+        fam = [d for n_, d in kt.summary().items() if n_.startswith("cm_gemm_h3") and d["flops"]]   # cm_gemm_h3 / _pb / _wgrad
         gk = {k_: sum(d[k_] for d in fam) for k_ in ("flops", "ms", "calls")} if fam else None
         if gk:
             alg = gk["flops"] / (gk["ms"] * 1e-3) / 1e12
-            roof = {"kernel": "gemm_h3_kernel (cm_gemm_h3 / cm_gemm_h3_wgrad: linear layers, stride-2 convs as im2col GEMMs, their gradients; fp16x3)",
+            roof = {"kernel": "gemm_h3_kernel (cm_gemm_h3_pb / cm_gemm_h3_wgrad: linear layers, stride-2 convs as im2col GEMMs, their gradients; fp16x3)",
                     "bound": "mfma", "achieved": round(3 * alg, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(3 * alg / PEAK_BF16_MFMA_TFLOPS, 4), "algorithmic_tflops": round(alg, 2),
                     "traffic": None, "launches_per_step": gk["calls"] / args.profile_steps,

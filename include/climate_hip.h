@@ -390,6 +390,20 @@ int cm_gemm_h3(const float* a, long long lda, int trans_a, const float* b, long 
  * STORES dw (as cm_gemm_h3 does); dbias always accumulates.                                                            */
 int cm_gemm_h3_wgrad(const float* dy, long long ld_dy, const float* x, long long ldx, float* dw, long long ld_dw,
                      float* dbias, int n_out, int k_in, int tokens, int ksplit, int tile, cm_stream stream);
+/* The same GEMM with the B operand split ONCE per step instead of inside every workgroup of every launch (the weight of a
+ * linear layer is the B operand of its forward and of its data-gradient GEMM; F.linear and its backward,
+ * src/cnn_transformer.py:26-33).  cm_gemm_h3_pack_b_batch: job table on the device, int64 x 8 per job = {w, out, be, N, K,
+ * ld, trans, first_block}: B[n][k] = w[n * ld + k] (trans = 0: the forward's W [out][in]) or w[k * ld + n] (trans = 1: the
+ * data gradient's view of the same storage); `be` (one unsigned per job, zeroed by the caller) receives the biased exponent
+ * of max |w|, `out` (cm_gemm_h3_packed_b_bytes(N, K) bytes) the fp16 pieces scaled by 2^(140 - max(be, 13)) in the kernel's
+ * LDS image order; first_block = running sum of ceil(N/64) * ceil(K/64) * 2 over the jobs, total_blocks the sum over all.
+ * cm_gemm_h3_pb: C = epilogue(A B^T) as cm_gemm_h3 with trans_a = trans_b = 0, ksplit = 1, 64 x 64 tiles.                */
+long long cm_gemm_h3_packed_b_bytes(int n, int k);
+int cm_gemm_h3_pack_b_batch(const long long* table, int njobs, int total_blocks, int amax_blocks, cm_stream stream);
+int cm_gemm_h3_pb(const float* a, long long lda, const void* b_packed, const unsigned* b_exp, float* c, long long ldc,
+                  const float* bias, const float* resid, long long ldr, int res_rows, const float* mask, long long ldm,
+                  float mask_scale, int relu, const unsigned* rng, unsigned site, float drop_p, int m, int n, int k,
+                  cm_stream stream);
 /* post-norm residual LayerNorm, eps as given (nn.LayerNorm default 1e-5): sum_out = x + resid (nullable resid; kept for
  * the backward), y = LN(sum_out) * gamma + beta, stats[m][2] = {mean, rstd}.  e <= 1024.                          */
 int cm_layernorm_fwd(const float* x, const float* resid, const float* gamma, const float* beta, float* sum_out, float* y,

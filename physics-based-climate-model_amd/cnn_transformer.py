@@ -37,13 +37,45 @@ class _Saved:
     pass
 
 
-def forward(p: Dict[str, Tensor], x: Tensor, n_heads: int, save: bool = True, head: bool = True, drop=None):
+def _weight_views(p: Dict[str, Tensor]):
+    """name -> 2-D [out, in] view of every weight that is the B operand of a GEMM (linear layers; the two stride-2 convs as
+    im2col GEMMs)."""
+    out = {"encoder.0.weight": p["encoder.0.weight"].view(p["encoder.0.weight"].shape[0], -1),
+           "encoder.2.weight": p["encoder.2.weight"].view(p["encoder.2.weight"].shape[0], -1)}
+    for k, v in p.items():
+        if k.startswith("transformer.layers.") and k.endswith(("in_proj_weight", "out_proj.weight", "linear1.weight",
+                                                                 "linear2.weight")):
+            out[k] = v
+    return out
+
+
+def pack_weights(p: Dict[str, Tensor], device) -> "ops.PackedWeights":
+    """fp16x3 B operands of every GEMM weight, both orientations: key ``name`` for the forward (rows = out features) and
+    ``name + "/d"`` for the data gradient (rows = in features).  ``.pack()`` refreshes them from the current parameters."""
+    pw = ops.PackedWeights(device)
+    for k, w in _weight_views(p).items():
+        n_out, k_in = w.shape
+        pw.add(k, w, n_out, k_in, trans=False)
+        pw.add(k + "/d", w, k_in, n_out, trans=True)
+    return pw
+
+
+def _lin(x, p, name, pw, m, n, k, key=None, **kw):
+    """x @ B^T with B = the weight ``name`` ([n, k] view) -- from the packed operands when they are given."""
+    if pw is not None:
+        return ops.gemm_pb(x, pw[key or name], m, **kw)
+    w = p[name]
+    return ops.gemm(x, w.view(w.shape[0], -1), m, n, k, **kw)
+
+
+def forward(p: Dict[str, Tensor], x: Tensor, n_heads: int, save: bool = True, head: bool = True, drop=None, pw=None):
     """x [B, Cin, H, W] (H, W multiples of 4) -> pred [B, out, H, W], saved activations.
 
     ``drop`` = (rng, p) turns on the four dropouts of every encoder layer (attention probabilities, after the attention
     block, inside the MLP, after the MLP: nn.TransformerEncoderLayer(dropout=p), reference src/cnn_transformer.py:26-33)
     with counter-based masks: site 4*layer + {0, 1, 2, 3}; rng is this call's {seed, counter} snapshot (kept in the
-    saved state: the backward regenerates the masks from it)."""
+    saved state: the backward regenerates the masks from it).  ``pw``: ops.PackedWeights of this parameter set, packed from
+    the CURRENT values (pack_weights(p).pack()); without it every GEMM splits its weight operand itself."""
     if x.dim() != 4:
         raise RuntimeError("expected x of shape [B, C, H, W]")
     B, Cin, H, W = x.shape
@@ -59,10 +91,10 @@ def forward(p: Dict[str, Tensor], x: Tensor, n_heads: int, save: bool = True, he
     x = x.contiguous()
     k1 = Cin * 9
     col1 = ops.im2col_s2(x, B, Cin, H, W, (k1 + 3) // 4 * 4, tokens_in=False)
-    y1 = ops.gemm(col1, p["encoder.0.weight"].view(E2, k1), M1, E2, k1, bias=p["encoder.0.bias"], relu=True)
+    y1 = _lin(col1, p, "encoder.0.weight", pw, M1, E2, k1, bias=p["encoder.0.bias"], relu=True)
     col2 = ops.im2col_s2(y1, B, E2, H // 2, W // 2, E2 * 9, tokens_in=True)
     pos = p["pos_embedding"].view(S, E)
-    t0 = ops.gemm(col2, p["encoder.2.weight"].view(E, E2 * 9), M, E, E2 * 9, bias=p["encoder.2.bias"], relu=True)
+    t0 = _lin(col2, p, "encoder.2.weight", pw, M, E, E2 * 9, bias=p["encoder.2.bias"], relu=True)
     t = _add_pos(t0, pos, S)            # the ReLU output t0 is kept: it is the mask of the conv's backward
     depth = 1 + max(int(k.split(".")[2]) for k in p if k.startswith("transformer.layers."))
     layers = []
@@ -70,12 +102,12 @@ def forward(p: Dict[str, Tensor], x: Tensor, n_heads: int, save: bool = True, he
         q = f"transformer.layers.{i}."
         mlp = p[q + "linear1.weight"].shape[0]
         dr = [None] * 4 if drop is None else [(drop[0], 4 * i + k, drop[1]) for k in range(4)]
-        qkv = ops.gemm(t, p[q + "self_attn.in_proj_weight"], M, 3 * E, E, bias=p[q + "self_attn.in_proj_bias"])
+        qkv = _lin(t, p, q + "self_attn.in_proj_weight", pw, M, 3 * E, E, bias=p[q + "self_attn.in_proj_bias"])
         P, o = ops.attention_fwd(qkv, B, S, E, n_heads, drop=dr[0])
-        a = ops.gemm(o, p[q + "self_attn.out_proj.weight"], M, E, E, bias=p[q + "self_attn.out_proj.bias"], drop=dr[1])
+        a = _lin(o, p, q + "self_attn.out_proj.weight", pw, M, E, E, bias=p[q + "self_attn.out_proj.bias"], drop=dr[1])
         t1, s1, st1 = ops.layernorm_fwd(a, t, p[q + "norm1.weight"], p[q + "norm1.bias"])
-        h1 = ops.gemm(t1, p[q + "linear1.weight"], M, mlp, E, bias=p[q + "linear1.bias"], relu=True, drop=dr[2])
-        m2 = ops.gemm(h1, p[q + "linear2.weight"], M, E, mlp, bias=p[q + "linear2.bias"], drop=dr[3])
+        h1 = _lin(t1, p, q + "linear1.weight", pw, M, mlp, E, bias=p[q + "linear1.bias"], relu=True, drop=dr[2])
+        m2 = _lin(h1, p, q + "linear2.weight", pw, M, E, mlp, bias=p[q + "linear2.bias"], drop=dr[3])
         t2, s2, st2 = ops.layernorm_fwd(m2, t1, p[q + "norm2.weight"], p[q + "norm2.bias"])
         if save:
             layers.append((t, qkv, P, o, s1, st1, t1, h1, s2, st2))
@@ -91,6 +123,7 @@ def forward(p: Dict[str, Tensor], x: Tensor, n_heads: int, save: bool = True, he
         sv.dec1, sv.dec2 = d1, d2         # decoder activations (post-ReLU)
         sv.d1 = d2                        # input of the 1x1 head: what the fused trainer's head+MSE launch reads
         sv.drop = drop
+        sv.pw = pw
     return pred, sv
 
 
@@ -101,6 +134,14 @@ def _add_pos(t0: Tensor, pos: Tensor, S: int) -> Tensor:
     check(lib.cm_add_rowgroup(t0.data_ptr(), pos.data_ptr(), out.data_ptr(), t0.shape[0], t0.shape[1], S,
                               torch.cuda.current_stream().cuda_stream), "add_rowgroup")
     return out
+
+
+def _dlin(dy, p, name, pw, m, n, k, **kw):
+    """dy @ W (the data gradient of x W^T: B rows = in features, stored across the weight's rows)."""
+    if pw is not None:
+        return ops.gemm_pb(dy, pw[name + "/d"], m, **kw)
+    w = p[name]
+    return ops.gemm(dy, w.view(w.shape[0], -1), m, n, k, trans_b=True, **kw)
 
 
 def _wgrad(dy: Tensor, x: Tensor, dw: Tensor, n_out: int, k_in: int, tokens: int, dbias: Tensor = None):
@@ -120,6 +161,7 @@ def backward(p: Dict[str, Tensor], g: Dict[str, Tensor], sv, n_heads: int, dpred
     S = (H // 4) * (W // 4)
     E2, E = p["encoder.0.weight"].shape[0], p["encoder.2.weight"].shape[0]
     M1, M = B * (H // 2) * (W // 2), B * S
+    pw = getattr(sv, "pw", None)
     if dd_head is None:
         dd_head = ops.head_bwd(dpred, sv.dec2, p["decoder.4.weight"], g["decoder.4.weight"], g["decoder.4.bias"])
     dd2 = ops.relu_mask_(dd_head, sv.dec2)
@@ -140,25 +182,25 @@ def backward(p: Dict[str, Tensor], g: Dict[str, Tensor], sv, n_heads: int, dpred
                                      drop=dr[3], dbias=g[q + "linear2.bias"])
         _wgrad(dm2, h1, g[q + "linear2.weight"], E, mlp, M)
         # through linear2, the MLP dropout and the ReLU: h1 is the DROPPED activation, so h1 > 0 <=> kept and positive
-        dh1 = ops.gemm(dm2, p[q + "linear2.weight"], M, mlp, E, trans_b=True, mask=h1, mask_scale=keep_scale)
+        dh1 = _dlin(dm2, p, q + "linear2.weight", pw, M, mlp, E, mask=h1, mask_scale=keep_scale)
         _wgrad(dh1, t1, g[q + "linear1.weight"], mlp, E, M, dbias=g[q + "linear1.bias"])
-        dt1 = ops.gemm(dh1, p[q + "linear1.weight"], M, E, mlp, trans_b=True, resid=ds2, res_rows=M)   # + residual branch
+        dt1 = _dlin(dh1, p, q + "linear1.weight", pw, M, E, mlp, resid=ds2, res_rows=M)   # + residual branch
         ds1, da = ops.layernorm_bwd(s1, st1, p[q + "norm1.weight"], dt1, g[q + "norm1.weight"], g[q + "norm1.bias"],
                                     drop=dr[1], dbias=g[q + "self_attn.out_proj.bias"])
         _wgrad(da, o, g[q + "self_attn.out_proj.weight"], E, E, M)
-        d_o = ops.gemm(da, p[q + "self_attn.out_proj.weight"], M, E, E, trans_b=True)
+        d_o = _dlin(da, p, q + "self_attn.out_proj.weight", pw, M, E, E)
         dqkv = ops.attention_bwd(qkv, P, d_o, B, S, E, n_heads, drop=dr[0], o=o)
         _wgrad(dqkv, t_in, g[q + "self_attn.in_proj_weight"], 3 * E, E, M, dbias=g[q + "self_attn.in_proj_bias"])
-        dt = ops.gemm(dqkv, p[q + "self_attn.in_proj_weight"], M, E, 3 * E, trans_b=True, resid=ds1, res_rows=M)
+        dt = _dlin(dqkv, p, q + "self_attn.in_proj_weight", pw, M, E, 3 * E, resid=ds1, res_rows=M)
     ops.rowgroup_sum(dt, g["pos_embedding"].view(S, E), period=S)
     dt0 = ops.relu_mask_(dt, sv.t0)
     _wgrad(dt0, sv.col2, g["encoder.2.weight"], E, E2 * 9, M, dbias=g["encoder.2.bias"])
-    dcol2 = ops.gemm(dt0, p["encoder.2.weight"].view(E, E2 * 9), M, E2 * 9, E, trans_b=True)
+    dcol2 = _dlin(dt0, p, "encoder.2.weight", pw, M, E2 * 9, E)
     dy1 = ops.relu_mask_(ops.col2im_s2(dcol2, B, E2, H // 2, W // 2), sv.y1)
     _wgrad(dy1, sv.col1, g["encoder.0.weight"], E2, Cin * 9, M1, dbias=g["encoder.0.bias"])
     if not need_dx:
         return None
-    dcol1 = ops.gemm(dy1, p["encoder.0.weight"].view(E2, Cin * 9), M1, Cin * 9, E2, trans_b=True)
+    dcol1 = _dlin(dy1, p, "encoder.0.weight", pw, M1, Cin * 9, E2)
     dx_tok = ops.col2im_s2(dcol1, B, Cin, H, W)                     # token-major [B*H*W, Cin]
     return ops.transpose_batched(dx_tok.view(B, H * W, Cin), B, H * W, Cin).view(B, Cin, H, W)
 
@@ -204,7 +246,21 @@ class CNNTransformer(_HipModule):
         dev = next(self.parameters()).device
         self.__dict__["_rng"] = torch.tensor([int(seed) & 0x7fffffff, int(counter)], dtype=torch.int32, device=dev)
 
-    def _engine_forward(self, p, pk, x, save=True, head=True, rng_snapshot=None):
+    def _packed_weights(self, p, device):
+        """This parameter set's packed GEMM operands (built once per flat parameter buffer; ``.pack()`` refreshes them)."""
+        key = (str(device), p["encoder.0.weight"].data_ptr())
+        cache = self.__dict__.setdefault("_pw_cache", {})
+        if key not in cache:
+            cache.clear()
+            cache[key] = pack_weights(p, device)
+        return cache[key]
+
+    def _engine_forward(self, p, pk, x, save=True, head=True, rng_snapshot=None, packed=False):
+        # the weight operands are split once per forward (3 launches) -- or once per STEP by the caller that runs several
+        # forwards of the same parameters side by side (_micro_prepare: packed=True)
+        pw = self._packed_weights(p, x.device)
+        if not packed:
+            pw.pack()
         drop = None
         if self.training and self.dropout_p > 0.0:
             if rng_snapshot is None:
@@ -213,20 +269,21 @@ class CNNTransformer(_HipModule):
                 # this call's snapshot: a later forward (gradient accumulation) must not change the masks of this backward
                 rng_snapshot = rng.clone()
             drop = (rng_snapshot, self.dropout_p)
-        return forward(p, x, self.n_heads, save=save, head=head, drop=drop)
+        return forward(p, x, self.n_heads, save=save, head=head, drop=drop, pw=pw)
 
     def _micro_prepare(self, device, parts: int):
         """Per-micro-batch keyword arguments of ``_engine_forward`` for forwards that run CONCURRENTLY (the trainer's
         micro-batch overlap): the dropout counter is advanced once per part here, on the caller's stream, and every part
         gets its own {seed, counter} snapshot -- two forwards advancing the device counter from two streams would race
-        and could draw the same masks."""
+        and could draw the same masks.  The weight operands are packed here too, once for all parts."""
+        self._packed_weights(self._param_dict(), device).pack()       # once, on the caller's stream, for all parts
         if not (self.training and self.dropout_p > 0.0):
-            return [{} for _ in range(parts)]
+            return [{"packed": True} for _ in range(parts)]
         rng = self._rng_state(device)
         out = []
         for _ in range(parts):
             ops.rng_advance(rng)
-            out.append({"rng_snapshot": rng.clone()})
+            out.append({"rng_snapshot": rng.clone(), "packed": True})
         return out
 
     def _engine_backward(self, p, pk, g, sv, dpred, need_dx=False, dd1=None):

@@ -36,6 +36,8 @@ struct GemmArgs {
   float drop_p;
   float mask_scale;       // factor on the elements the mask keeps (ReLU backward through a DROPPED activation: 1/(1-p))
   float* a_rowsum;        // [M] or null (transposed A only): += sum over k of op(A)[m][k] -- with A = dY^T the bias gradient
+  const gu32x4* Bp;       // packed B (cm_gemm_h3_pack_b_batch): [n tile of 64][32-deep image][piece][k octet][row] records
+  const unsigned* bexp;   // ... and the biased exponent of its tensor's max |b| (the scale the packer used)
 };
 
 constexpr int GBM = 128, GBN = 128, GBK = 32;
@@ -148,9 +150,10 @@ __device__ __forceinline__ void gemm_store_tile64(gu32x4* __restrict__ L, int ti
 // staging arithmetic behind).
 // BM = BN = 64: 2 x 2 waves of 32 x 32 (four times the workgroups: for the GEMMs whose 128 x 64 tiling still leaves the
 // chip under ~4 workgroups per CU).
-template <bool TA, bool TB, int BN = 128, int BM = 128, int NHALF = 2>
+template <bool TA, bool TB, int BN = 128, int BM = 128, int NHALF = 2, bool PB = false>
 __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
   static_assert(BM == 128 || (BM == 64 && BN == 64), "tile shapes: 128x128, 128x64, 64x64");
+  static_assert(!PB || (BM == 64 && BN == 64 && !TB), "packed B: 64 x 64 tiles (its orientation is fixed by the packer)");
   constexpr int TI = (BM == 128 && BN == 128) ? 2 : 1, TJ = BM == 64 ? 1 : 2;
   constexpr int NH = (BM == 64 && BN == 64) ? NHALF : 1;      // 32-deep images per stage (64 x 64 tiles only)
   constexpr int LP = NH * 64 > 128 ? NH * 64 : 128;           // row pitch of the LDS images
@@ -181,8 +184,33 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
     else gemm_load_tile64<TA>(a.A, a.lda, a.M, a.K, m0, k0, tid, v);
   };
   auto load_b = [&](int k0, float (&v)[16]) {
-    if constexpr (BN == 128) gemm_load_tile<TB>(a.B, a.ldb, a.N, a.K, n0, k0, tid, v);
+    if constexpr (PB) return;
+    else if constexpr (BN == 128) gemm_load_tile<TB>(a.B, a.ldb, a.N, a.K, n0, k0, tid, v);
     else gemm_load_tile64<TB>(a.B, a.ldb, a.N, a.K, n0, k0, tid, v);
+  };
+  // packed B: image (n tile, 32-deep step) is 512 ready-made records; a thread moves records tid and tid + 256
+  gu32x4 pbr[PB ? NH : 1][2];
+  const long long nimg = (long long)((a.K + SK - 1) / SK) * NH;              // images per n tile (K padded by the packer)
+  auto load_pb = [&](int s) {
+    if constexpr (PB) {
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const gu32x4* src = a.Bp + ((long long)blockIdx.x * nimg + (long long)s * NH + h) * 512;
+        pbr[h][0] = src[tid];
+        pbr[h][1] = src[tid + 256];
+      }
+    }
+  };
+  auto store_pb = [&]() {
+    if constexpr (PB) {
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int r = tid + 256 * i;                   // r = (piece*4 + octet)*64 + row
+          Bl[(r >> 6) * LP + h * 64 + (r & 63)] = pbr[h][i];
+        }
+    }
   };
 
   if (tid < 4) smax[tid >> 1][tid & 1] = 0u;
@@ -191,25 +219,33 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
   float rsum[2] = {0.f, 0.f};
   const bool sum_rows = TA && a.a_rowsum != nullptr && blockIdx.x == 0;     // (the first column of tiles does it once)
   unsigned bea = 0, beb = 0;                 // biased exponents of the running maxima
+  const unsigned beb_fixed = PB ? a.bexp[0] : 0u;        // packed B: one scale for the whole tensor, known up front
   auto post = [&](int par) {
     float ma = 0.f, mb = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { ma = fmaxf(ma, fabsf(va[i])); mb = fmaxf(mb, fabsf(vb[i])); }
+    for (int i = 0; i < 16; ++i) {
+      ma = fmaxf(ma, fabsf(va[i]));
+      if constexpr (!PB) mb = fmaxf(mb, fabsf(vb[i]));
+    }
     if constexpr (NH > 1) {
 #pragma unroll
       for (int h = 0; h < NH - 1; ++h)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { ma = fmaxf(ma, fabsf(va2[h][i])); mb = fmaxf(mb, fabsf(vb2[h][i])); }
+        for (int i = 0; i < 8; ++i) {
+          ma = fmaxf(ma, fabsf(va2[h][i]));
+          if constexpr (!PB) mb = fmaxf(mb, fabsf(vb2[h][i]));
+        }
     }
     ma = wave_max_nonneg(ma);
-    mb = wave_max_nonneg(mb);
+    if constexpr (!PB) mb = wave_max_nonneg(mb);
     if (lane == 0) {
       atomicMax(&smax[par][0], __float_as_uint(ma));
-      atomicMax(&smax[par][1], __float_as_uint(mb));
+      if constexpr (!PB) atomicMax(&smax[par][1], __float_as_uint(mb));
     }
   };
   load_a(s_begin * SK, va);
   load_b(s_begin * SK, vb);
+  load_pb(s_begin);
   if constexpr (NH > 1) {
 #pragma unroll
     for (int h = 0; h < NH - 1; ++h) {
@@ -221,7 +257,8 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
   __syncthreads();
   for (int s = s_begin; s < s_end; ++s) {
     const int par = (s - s_begin) & 1;
-    const unsigned na = max(bea, (smax[par][0] >> 23) & 0xffu), nb = max(beb, (smax[par][1] >> 23) & 0xffu);
+    const unsigned na = max(bea, (smax[par][0] >> 23) & 0xffu);
+    const unsigned nb = PB ? beb_fixed : max(beb, (smax[par][1] >> 23) & 0xffu);
     if (na != bea || nb != beb) {            // (workgroup uniform) a scale shrank: the accumulators follow
       if (bea != 0 || beb != 0) {
         const int d = (int)(max(na, 13u) - max(bea, 13u)) + (int)(max(nb, 13u) - max(beb, 13u));
@@ -250,13 +287,14 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
     }
     if constexpr (BM == 128) gemm_store_tile<TA>(Al, tid, va, sa);
     else gemm_store_tile64<TA, LP>(Al, tid, va, sa);
-    if constexpr (BN == 128) gemm_store_tile<TB>(Bl, tid, vb, sb);
+    if constexpr (PB) store_pb();
+    else if constexpr (BN == 128) gemm_store_tile<TB>(Bl, tid, vb, sb);
     else gemm_store_tile64<TB, LP>(Bl, tid, vb, sb);
     if constexpr (NH > 1) {
 #pragma unroll
       for (int h = 0; h < NH - 1; ++h) {
         gemm_store_tile64<TA, LP>(Al + 64 * (h + 1), tid, va2[h], sa);
-        gemm_store_tile64<TB, LP>(Bl + 64 * (h + 1), tid, vb2[h], sb);
+        if constexpr (!PB) gemm_store_tile64<TB, LP>(Bl + 64 * (h + 1), tid, vb2[h], sb);
       }
     }
     __syncthreads();
@@ -264,6 +302,7 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
     if (s + 1 < s_end) {
       load_a((s + 1) * SK, va);
       load_b((s + 1) * SK, vb);
+      load_pb(s + 1);
       if constexpr (NH > 1) {
 #pragma unroll
         for (int h = 0; h < NH - 1; ++h) {
@@ -337,14 +376,88 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
     }
 }
 
+// ---- packed B operand -------------------------------------------------------------------------------------------------
+// A weight matrix is the B operand of the forward (W [out][in]: rows n = out, k = in) and of the data gradient (rows n = in,
+// k = out: the same storage read across) GEMMs of every step; splitting it inside every workgroup of every launch was
+// half of the kernel's staging arithmetic.  The packer does it once per step and orientation:
+//   job table (int64 x 8 per job): {w, out, be, N, K, ld, trans, first_block}; trans = 1: B[n][k] = w[k * ld + n].
+//   pass 1 (amax): be[job] = max over the tensor of the biased exponent of |w| (atomic max of the float bits >> 23);
+//   pass 2 (pack): block = (n tile of 64, 32-deep image): 512 records of 8 consecutive k of one row, scaled by
+//   2^(140 - max(be, 13)) and split into fp16 pieces exactly as gemm_store_tile64 does; rows >= N and k >= K hold zeros.
+__global__ __launch_bounds__(256) void gemm_pack_amax_kernel(const long long* __restrict__ table, int njobs) {
+  const int job = blockIdx.y;
+  if (job >= njobs) return;
+  const long long* t = table + (long long)job * 8;
+  const float* w = reinterpret_cast<const float*>(t[0]);
+  unsigned* be = reinterpret_cast<unsigned*>(t[2]);
+  const long long rows = t[6] ? t[4] : t[3], cols = t[6] ? t[3] : t[4], ld = t[5];     // storage rows x cols
+  float m = 0.f;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < rows * cols; i += 256LL * gridDim.x)
+    m = fmaxf(m, fabsf(w[(i / cols) * ld + i % cols]));
+  m = wave_max_nonneg(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(be, __float_as_uint(m) >> 23 & 0xffu);
+}
+
+__global__ __launch_bounds__(256) void gemm_pack_b_kernel(const long long* __restrict__ table, int njobs) {
+  int job = 0;
+  for (int j = 1; j < njobs; ++j)
+    if ((long long)blockIdx.x >= table[(long long)j * 8 + 7]) job = j;             // (first_block ascending)
+  const long long* t = table + (long long)job * 8;
+  const float* w = reinterpret_cast<const float*>(t[0]);
+  gu32x4* out = reinterpret_cast<gu32x4*>(t[1]);
+  const unsigned be = *reinterpret_cast<const unsigned*>(t[2]);
+  const int N = (int)t[3], K = (int)t[4];
+  const long long ld = t[5];
+  const bool trans = t[6] != 0;
+  const int blk = (int)(blockIdx.x - t[7]);
+  const int nimg = ((K + 63) / 64) * 2;                 // images per n tile (K padded to the 64-deep stage)
+  const int ntile = blk / nimg, img = blk % nimg;
+  const float sc = __uint_as_float((267u - max(be, 13u)) << 23);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = threadIdx.x + 256 * i;                // r = (piece*4 + octet)*64 + row; this thread makes BOTH pieces of
+    if (r >= 256) continue;                             // (octet, row) = r when r < 256
+    const int oct = r >> 6, row = r & 63;
+    const int n = ntile * 64 + row, k0 = img * 32 + oct * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + j;
+      v[j] = (n < N && k < K) ? (trans ? w[(long long)k * ld + n] : w[(long long)n * ld + k]) : 0.f;
+    }
+    gu32x4 ph, pl;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned a_, b_;
+      split2_pair_f16(v[2 * q] * sc, v[2 * q + 1] * sc, a_, b_);
+      ph[q] = a_; pl[q] = b_;
+    }
+    out[(long long)blk * 512 + r] = ph;
+    out[(long long)blk * 512 + 256 + r] = pl;
+  }
+}
+
 }  // namespace
 
 extern "C" {
 
+long long cm_gemm_h3_packed_b_bytes(int n, int k) { return (long long)cdiv(n, 64) * cdiv(k, 64) * 2 * 512 * 16; }
+
+int cm_gemm_h3_pack_b_batch(const long long* table, int njobs, int total_blocks, int amax_blocks, cm_stream stream) {
+  if (!table || njobs <= 0 || total_blocks <= 0 || amax_blocks <= 0) return -22;
+  hipStream_t st = (hipStream_t)stream;
+  gemm_pack_amax_kernel<<<dim3(amax_blocks, njobs), 256, 0, st>>>(table, njobs);
+  CM_CHECK_LAUNCH();
+  gemm_pack_b_kernel<<<total_blocks, 256, 0, st>>>(table, njobs);
+  CM_CHECK_LAUNCH();
+  return 0;
+}
+
 static int gemm_h3_launch(const float* a, long long lda, int trans_a, const float* b, long long ldb, int trans_b, float* c,
                           long long ldc, const float* bias, const float* resid, long long ldr, int res_rows,
                           const float* mask, long long ldm, float mask_scale, int relu, const unsigned* rng, unsigned site,
-                          float drop_p, int m, int n, int k, int ksplit, int tile, float* a_rowsum, cm_stream stream);
+                          float drop_p, int m, int n, int k, int ksplit, int tile, float* a_rowsum, cm_stream stream,
+                          const void* b_packed = nullptr, const unsigned* b_exp = nullptr);
 
 int cm_gemm_h3(const float* a, long long lda, int trans_a, const float* b, long long ldb, int trans_b, float* c,
                long long ldc, const float* bias, const float* resid, long long ldr, int res_rows, const float* mask,
@@ -360,10 +473,20 @@ int cm_gemm_h3_wgrad(const float* dy, long long ld_dy, const float* x, long long
                         n_out, k_in, tokens, ksplit, tile, dbias, stream);
 }
 
+int cm_gemm_h3_pb(const float* a, long long lda, const void* b_packed, const unsigned* b_exp, float* c, long long ldc,
+                  const float* bias, const float* resid, long long ldr, int res_rows, const float* mask, long long ldm,
+                  float mask_scale, int relu, const unsigned* rng, unsigned site, float drop_p, int m, int n, int k,
+                  cm_stream stream) {
+  if (!b_packed || !b_exp) return -22;
+  return gemm_h3_launch(a, lda, 0, a, 1, 0, c, ldc, bias, resid, ldr, res_rows, mask, ldm, mask_scale, relu, rng, site, drop_p,
+                        m, n, k, 1, 3, nullptr, stream, b_packed, b_exp);
+}
+
 static int gemm_h3_launch(const float* a, long long lda, int trans_a, const float* b, long long ldb, int trans_b, float* c,
                           long long ldc, const float* bias, const float* resid, long long ldr, int res_rows,
                           const float* mask, long long ldm, float mask_scale, int relu, const unsigned* rng, unsigned site,
-                          float drop_p, int m, int n, int k, int ksplit, int tile, float* a_rowsum, cm_stream stream) {
+                          float drop_p, int m, int n, int k, int ksplit, int tile, float* a_rowsum, cm_stream stream,
+                          const void* b_packed, const unsigned* b_exp) {
   if (m <= 0 || n <= 0 || k <= 0 || !a || !b || !c || lda <= 0 || ldb <= 0 || ldc < n) return -22;
   if (ksplit < 1) ksplit = 1;
   if (ksplit > 1 && (resid || mask || relu || (rng && drop_p > 0.f))) return -22;   // split K accumulates raw sums
@@ -376,6 +499,14 @@ static int gemm_h3_launch(const float* a, long long lda, int trans_a, const floa
   g.M = m; g.N = n; g.K = k; g.res_rows = res_rows > 0 ? res_rows : m; g.relu = relu;
   g.rng = drop_p > 0.f ? rng : nullptr; g.site = site; g.drop_p = drop_p; g.mask_scale = mask_scale;
   g.a_rowsum = a_rowsum;
+  g.Bp = reinterpret_cast<const gu32x4*>(b_packed); g.bexp = b_exp;
+  if (b_packed) {        // packed B: 64 x 64 tiles, 64-deep stages (the packer's image size), A stored [m][k]
+    if (trans_a || ksplit != 1) return -22;
+    g.ksplit = 1;
+    gemm_h3_kernel<false, false, 64, 64, 2, true><<<dim3(cdiv(n, 64), cdiv(m, 64), 1), 256, 0, (hipStream_t)stream>>>(g);
+    CM_CHECK_LAUNCH();
+    return 0;
+  }
   const int nstage = cdiv(k, GBK);              // (the 64 x 64 kernel counts 64-deep stages itself: empty shares return)
   g.ksplit = ksplit > nstage ? nstage : ksplit;
   hipStream_t st = (hipStream_t)stream;

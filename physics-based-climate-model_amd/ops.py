@@ -834,6 +834,58 @@ def gemm(a, b, m, n, k, trans_a=False, trans_b=False, bias=None, resid=None, res
     return out
 
 
+class PackedWeights:
+    """fp16x3 B operands of a set of weight matrices, split once per step (cm_gemm_h3_pack_b_batch): ``add(key, w, n, k,
+    trans)`` registers B[n][k] = w[n, k] (trans False) or w[k, n] (trans True) of a 2-D view ``w``; ``pack()`` (3 launches)
+    refreshes all of them from the current values; ``gemm_pb`` consumes ``self[key]``."""
+
+    def __init__(self, device):
+        self.device = device
+        self.jobs = []
+        self.index = {}
+        self.table = None
+
+    def add(self, key, w, n, k, trans=False):
+        if w.dim() != 2 or w.stride(1) != 1:
+            raise RuntimeError("PackedWeights.add needs a 2-D view with unit column stride")
+        self.index[key] = len(self.jobs)
+        self.jobs.append((w, int(n), int(k), bool(trans)))
+        self.table = None
+
+    def _build(self):
+        nb = [((n + 63) // 64) * ((k + 63) // 64) * 2 for _, n, k, _ in self.jobs]
+        self.out = [torch.empty(b * 512 * 4, device=self.device, dtype=torch.float32) for b in nb]
+        self.be = torch.zeros(len(self.jobs), device=self.device, dtype=torch.int32)
+        rows, first = [], 0
+        for j, (w, n, k, trans) in enumerate(self.jobs):
+            rows.append([w.data_ptr(), self.out[j].data_ptr(), self.be.data_ptr() + 4 * j, n, k, w.stride(0), int(trans), first])
+            first += nb[j]
+        self.total = first
+        self.table = torch.tensor(rows, dtype=torch.int64).to(self.device)
+
+    def pack(self):
+        if self.table is None:
+            self._build()
+        check(lib.cm_zero(self.be.data_ptr(), self.be.numel() * 4, _stream()), "zero")
+        check(lib.cm_gemm_h3_pack_b_batch(_p_any(self.table), len(self.jobs), self.total, 8, _stream()), "gemm_pack_b")
+
+    def __getitem__(self, key):
+        j = self.index[key]
+        return self.out[j], self.be[j:j + 1], self.jobs[j][1], self.jobs[j][2]
+
+
+def gemm_pb(a, packed, m, bias=None, resid=None, res_rows=0, mask=None, relu=False, out=None, drop=None, mask_scale=1.0):
+    """out[m, n] = epilogue(a [m, k] @ B^T) with ``packed`` = PackedWeights[key] (the B operand split once per step)."""
+    bp, be, n, k = packed
+    if out is None:
+        out = torch.empty(m, n, device=a.device, dtype=torch.float32)
+    check(lib.cm_gemm_h3_pb(_p(a), a.stride(0), _p(bp), _p_any(be), _p(out), out.stride(0), _p(bias), _p(resid),
+                            0 if resid is None else resid.stride(0), res_rows, _p(mask),
+                            0 if mask is None else mask.stride(0), float(mask_scale), int(relu), *_drop_args(drop), m, n, k,
+                            _stream()), "gemm_h3_pb")
+    return out
+
+
 def gemm_wgrad(dy, x, dw, n_out, k_in, tokens, ksplit, dbias=None, tile=0):
     """dw [n_out, k_in] += dy^T x (dy [tokens, n_out], x [tokens, >= k_in]) and, with ``dbias``, dbias [n_out] += the column
     sums of dy in the same launch (cm_gemm_h3_wgrad)."""

@@ -95,8 +95,18 @@ def _gemm_wgrad_bytes(a):
     return 4.0 * (t * n + t * k + n * k)
 
 
+def _gemm_pb_flops(a):     # cm_gemm_h3_pb(a, lda, bp, be, c, ldc, bias, resid, ldr, res_rows, mask, ldm, mask_scale, relu, rng, site, p, m, n, k, stream)
+    return 2.0 * a[17] * a[18] * a[19]
+
+
+def _gemm_pb_bytes(a):
+    m, n, k = a[17], a[18], a[19]
+    return 4.0 * (m * k + n * k + m * n)
+
+
 MODELS = {
     "cm_gemm_h3": (_gemm_flops, _gemm_bytes),           # ALGORITHMIC flops (x3 are executed)
+    "cm_gemm_h3_pb": (_gemm_pb_flops, _gemm_pb_bytes),
     "cm_gemm_h3_wgrad": (_gemm_wgrad_flops, _gemm_wgrad_bytes),
     "cm_conv3x3": (_conv_flops, _conv_bytes),
     "cm_conv3x3_split": (_conv_flops, _conv_bytes),     # same argument positions; ALGORITHMIC flops (x6 are executed)

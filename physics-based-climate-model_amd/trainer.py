@@ -415,10 +415,13 @@ class InferenceRunner:
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream(device=x.device)
+        # per-call state that concurrent forwards must not share (dropout counters, packed weight operands): prepared once
+        prep = getattr(self.model, "_micro_prepare", None)
+        kws = prep(x.device, 2) if prep is not None else [{}, {}]
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
-            p1, _ = self.model._engine_forward(p, pk, x[h:], save=False)
-        p0, _ = self.model._engine_forward(p, pk, x[:h], save=False)
+            p1, _ = self.model._engine_forward(p, pk, x[h:], save=False, **kws[1])
+        p0, _ = self.model._engine_forward(p, pk, x[:h], save=False, **kws[0])
         main.wait_stream(self._side)
         return torch.cat([p0, p1], 0)
 

@@ -68,6 +68,33 @@ def test_gemm_wgrad_with_bias_gradient(ops, tokens, n_out, k_in, tile):
         assert rel_l2(dw2, want_w) < 2e-6, ks
 
 
+@pytest.mark.parametrize("m,n,k", [(300, 70, 45), (129, 129, 33), (1024, 768, 256), (6912, 256, 1152), (13, 200, 130)])
+def test_gemm_with_packed_weight_operand(ops, m, n, k):
+    """cm_gemm_h3_pack_b_batch + cm_gemm_h3_pb: the weight operand split once (both storage orientations, several jobs in one
+    table), the GEMM and its epilogue against float64; repacking after the weights changed."""
+    a = rnd(m, k, seed=31); w = rnd(n, k, seed=32, scale=k ** -0.5); w2 = rnd(k, n, seed=33) * 3e-4
+    W = w.cuda(); WT = w.t().contiguous().cuda(); W2 = w2.cuda()
+    pw = ops.PackedWeights(torch.device("cuda"))
+    pw.add("f", W, n, k, False)
+    pw.add("t", WT, n, k, True)             # the same B read across the transposed storage
+    pw.add("other", W2, n, k, True)         # a second tensor of very different magnitude in the same table
+    pw.pack()
+    ref = a.double() @ w.double().t()
+    assert rel_l2(ops.gemm_pb(a.cuda(), pw["f"], m), ref) < 2e-6
+    assert rel_l2(ops.gemm_pb(a.cuda(), pw["t"], m), ref) < 2e-6
+    assert rel_l2(ops.gemm_pb(a.cuda(), pw["other"], m), a.double() @ w2.double()) < 2e-6
+    bias = rnd(n, seed=34); res = rnd(7, n, seed=35); msk = rnd(m, n, seed=36)
+    c = ops.gemm_pb(a.cuda(), pw["f"], m, bias=bias.cuda(), relu=True, resid=res.cuda(), res_rows=7, mask=msk.cuda())
+    want = torch.relu(ref + bias.double()) + res.double()[torch.arange(m) % 7]
+    assert rel_l2(c, torch.where(msk.double() > 0, want, torch.zeros_like(want))) < 2e-6
+    W.mul_(-7.5)                            # the parameters change in place (Adam): a new pack() must follow them
+    pw.pack()
+    assert rel_l2(ops.gemm_pb(a.cuda(), pw["f"], m), -7.5 * ref) < 2e-6
+    W.zero_()
+    pw.pack()
+    assert torch.equal(ops.gemm_pb(a.cuda(), pw["f"], m, bias=bias.cuda()), bias.cuda().expand(m, n))
+
+
 @pytest.mark.parametrize("amag,bmag", [(1e-9, 1.0), (3e7, 1e-6), (1e-18, 1e-14), (1e12, 1e9)])
 def test_gemm_fp16x3_any_magnitude(ops, amag, bmag):
     m, n, k = 200, 150, 300
