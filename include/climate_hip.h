@@ -393,9 +393,9 @@ int cm_gemm_h3_wgrad(const float* dy, long long ld_dy, const float* x, long long
 /* The same GEMM with the B operand split ONCE per step instead of inside every workgroup of every launch (the weight of a
  * linear layer is the B operand of its forward and of its data-gradient GEMM; F.linear and its backward,
  * src/cnn_transformer.py:26-33).  cm_gemm_h3_pack_b_batch: job table on the device, int64 x 8 per job = {w, out, be, N, K,
- * ld, trans, first_block}: B[n][k] = w[n * ld + k] (trans = 0: the forward's W [out][in]) or w[k * ld + n] (trans = 1: the
- * data gradient's view of the same storage); `be` (one unsigned per job, zeroed by the caller) receives the biased exponent
- * of max |w|, `out` (cm_gemm_h3_packed_b_bytes(N, K) bytes) the fp16 pieces scaled by 2^(140 - max(be, 13)) in the kernel's
+ * ld, flags, first_block}: B[n][k] = w[n * ld + k] (flags bit 0 clear: the forward's W [out][in]) or w[k * ld + n] (bit 0 set:
+ * the data gradient's view of the same storage); `be` (one unsigned per TENSOR, zeroed by the caller; flags bit 1: another
+ * job of the same tensor fills it -- the two orientations of a weight share one) receives the biased exponent of max |w|, `out` (cm_gemm_h3_packed_b_bytes(N, K) bytes) the fp16 pieces scaled by 2^(140 - max(be, 13)) in the kernel's
  * LDS image order; first_block = running sum of ceil(N/64) * ceil(K/64) * 2 over the jobs, total_blocks the sum over all.
  * cm_gemm_h3_pb: C = epilogue(A B^T) as cm_gemm_h3 with trans_a = trans_b = 0, ksplit = 1, 64 x 64 tiles.                */
 long long cm_gemm_h3_packed_b_bytes(int n, int k);

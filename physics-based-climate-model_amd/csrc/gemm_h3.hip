@@ -380,7 +380,8 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs a) {
 // A weight matrix is the B operand of the forward (W [out][in]: rows n = out, k = in) and of the data gradient (rows n = in,
 // k = out: the same storage read across) GEMMs of every step; splitting it inside every workgroup of every launch was
 // half of the kernel's staging arithmetic.  The packer does it once per step and orientation:
-//   job table (int64 x 8 per job): {w, out, be, N, K, ld, trans, first_block}; trans = 1: B[n][k] = w[k * ld + n].
+//   job table (int64 x 8 per job): {w, out, be, N, K, ld, flags, first_block}; flags bit 0: B[n][k] = w[k * ld + n], bit 1:
+//   the exponent `be` is filled by another job of the same tensor (both orientations of a weight share one).
 //   pass 1 (amax): be[job] = max over the tensor of the biased exponent of |w| (atomic max of the float bits >> 23);
 //   pass 2 (pack): block = (n tile of 64, 32-deep image): 512 records of 8 consecutive k of one row, scaled by
 //   2^(140 - max(be, 13)) and split into fp16 pieces exactly as gemm_store_tile64 does; rows >= N and k >= K hold zeros.
@@ -388,9 +389,10 @@ __global__ __launch_bounds__(256) void gemm_pack_amax_kernel(const long long* __
   const int job = blockIdx.y;
   if (job >= njobs) return;
   const long long* t = table + (long long)job * 8;
+  if (t[6] & 2) return;                                  // (flag 2: another job of the same tensor fills this exponent)
   const float* w = reinterpret_cast<const float*>(t[0]);
   unsigned* be = reinterpret_cast<unsigned*>(t[2]);
-  const long long rows = t[6] ? t[4] : t[3], cols = t[6] ? t[3] : t[4], ld = t[5];     // storage rows x cols
+  const long long rows = (t[6] & 1) ? t[4] : t[3], cols = (t[6] & 1) ? t[3] : t[4], ld = t[5];     // storage rows x cols
   float m = 0.f;
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < rows * cols; i += 256LL * gridDim.x)
     m = fmaxf(m, fabsf(w[(i / cols) * ld + i % cols]));
@@ -399,16 +401,21 @@ __global__ __launch_bounds__(256) void gemm_pack_amax_kernel(const long long* __
 }
 
 __global__ __launch_bounds__(256) void gemm_pack_b_kernel(const long long* __restrict__ table, int njobs) {
-  int job = 0;
-  for (int j = 1; j < njobs; ++j)
-    if ((long long)blockIdx.x >= table[(long long)j * 8 + 7]) job = j;             // (first_block ascending)
+  // which job owns this block: first_block ascending, so the job is the number of entries <= blockIdx.x minus one --
+  // counted 64 entries at a time across the lanes (one load latency instead of njobs dependent ones)
+  int job = -1;
+  for (int j0 = 0; j0 < njobs; j0 += 64) {
+    const int j = j0 + (threadIdx.x & 63);
+    const bool le = j < njobs && table[(long long)j * 8 + 7] <= (long long)blockIdx.x;
+    job += __popcll(__ballot(le));
+  }
   const long long* t = table + (long long)job * 8;
   const float* w = reinterpret_cast<const float*>(t[0]);
   gu32x4* out = reinterpret_cast<gu32x4*>(t[1]);
   const unsigned be = *reinterpret_cast<const unsigned*>(t[2]);
   const int N = (int)t[3], K = (int)t[4];
   const long long ld = t[5];
-  const bool trans = t[6] != 0;
+  const bool trans = (t[6] & 1) != 0;
   const int blk = (int)(blockIdx.x - t[7]);
   const int nimg = ((K + 63) / 64) * 2;                 // images per n tile (K padded to the 64-deep stage)
   const int ntile = blk / nimg, img = blk % nimg;
@@ -420,10 +427,16 @@ __global__ __launch_bounds__(256) void gemm_pack_b_kernel(const long long* __res
     const int oct = r >> 6, row = r & 63;
     const int n = ntile * 64 + row, k0 = img * 32 + oct * 8;
     float v[8];
+    if (!trans && n < N && k0 + 8 <= K && (ld & 3) == 0 && (((uintptr_t)w) & 15) == 0) {    // one row's 8 k: two 16-byte loads
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(w + (long long)n * ld + k0);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(w + (long long)n * ld + k0 + 4);
+      v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = k0 + j;
-      v[j] = (n < N && k < K) ? (trans ? w[(long long)k * ld + n] : w[(long long)n * ld + k]) : 0.f;
+      for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j;
+        v[j] = (n < N && k < K) ? (trans ? w[(long long)k * ld + n] : w[(long long)n * ld + k]) : 0.f;
+      }
     }
     gu32x4 ph, pl;
 #pragma unroll

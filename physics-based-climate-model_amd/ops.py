@@ -856,9 +856,14 @@ class PackedWeights:
         nb = [((n + 63) // 64) * ((k + 63) // 64) * 2 for _, n, k, _ in self.jobs]
         self.out = [torch.empty(b * 512 * 4, device=self.device, dtype=torch.float32) for b in nb]
         self.be = torch.zeros(len(self.jobs), device=self.device, dtype=torch.int32)
-        rows, first = [], 0
+        self.slot = list(range(len(self.jobs)))
+        rows, first, owner = [], 0, {}
         for j, (w, n, k, trans) in enumerate(self.jobs):
-            rows.append([w.data_ptr(), self.out[j].data_ptr(), self.be.data_ptr() + 4 * j, n, k, w.stride(0), int(trans), first])
+            tkey = (w.data_ptr(), w.stride(0), tuple(w.shape))
+            o = owner.setdefault(tkey, j)          # the first job of a tensor measures its magnitude; later ones reuse it
+            self.slot[j] = o
+            rows.append([w.data_ptr(), self.out[j].data_ptr(), self.be.data_ptr() + 4 * o, n, k, w.stride(0),
+                         int(trans) | (2 if o != j else 0), first])
             first += nb[j]
         self.total = first
         self.table = torch.tensor(rows, dtype=torch.int64).to(self.device)
@@ -870,8 +875,11 @@ class PackedWeights:
         check(lib.cm_gemm_h3_pack_b_batch(_p_any(self.table), len(self.jobs), self.total, 8, _stream()), "gemm_pack_b")
 
     def __getitem__(self, key):
+        if self.table is None:
+            self._build()
         j = self.index[key]
-        return self.out[j], self.be[j:j + 1], self.jobs[j][1], self.jobs[j][2]
+        o = self.slot[j]
+        return self.out[j], self.be[o:o + 1], self.jobs[j][1], self.jobs[j][2]
 
 
 def gemm_pb(a, packed, m, bias=None, resid=None, res_rows=0, mask=None, relu=False, out=None, drop=None, mask_scale=1.0):
