@@ -96,3 +96,17 @@ __host__ __device__ static inline int cdiv(long long a, long long b) { return (i
     hipError_t e__ = hipGetLastError();        \
     if (e__ != hipSuccess) return (int)e__;    \
   } while (0)
+// the job that owns this block: the descriptors' first blocks ascend (record ndesc holds the total), so it is the number of
+// first blocks <= blockIdx.x minus one -- counted 64 records at a time across the lanes (one load latency; the former
+// `while (descs[d + 1].first <= block) ++d` was up to ndesc DEPENDENT loads in every thread of both pack launches)
+__device__ __forceinline__ int cm_job_of_block(const long long* __restrict__ descs, int ndesc) {
+  int d = -1;
+  for (int j0 = 0; j0 < ndesc; j0 += 64) {
+    const int j = j0 + (threadIdx.x & 63);
+    const bool le = j < ndesc && descs[(long long)j * 8 + 7] <= (long long)blockIdx.x;
+    d += __popcll(__ballot(le));
+  }
+  return d;
+}
+
+

@@ -283,8 +283,7 @@ __global__ void zero_out_kernel(float* __restrict__ out, long long sto, int n, l
 // Batched packer: one launch re-packs every 3x3 weight of the model.  descs = (ndesc + 1) records of 8 int64:
 // {w ptr, wp ptr, cout, cin_total, c_off, cin, dgrad, first block}; the last record only carries the total block count.
 __global__ void pack_batch_kernel(const long long* __restrict__ descs, int ndesc) {
-  int d = 0;
-  while (d + 1 < ndesc && descs[(d + 1) * 8 + 7] <= (long long)blockIdx.x) ++d;
+  const int d = cm_job_of_block(descs, ndesc);
   const long long* r = descs + d * 8;
   const float* w = reinterpret_cast<const float*>(r[0]);
   float* wp = reinterpret_cast<float*>(r[1]);

@@ -547,8 +547,7 @@ __global__ __launch_bounds__(WAVES * 64, split_min_waves(WAVES, NPT, WM)) void c
 // scale only has to be of the right order, and whole tensors stream as contiguous 16-byte loads): partial[blockIdx.x].
 __global__ void weight_amax_batch_kernel(const long long* __restrict__ descs, int ndesc, float* __restrict__ partial) {
   __shared__ float red[4];
-  int d = 0;
-  while (d + 1 < ndesc && descs[(d + 1) * 8 + 7] <= (long long)blockIdx.x) ++d;
+  const int d = cm_job_of_block(descs, ndesc);
   const long long* r = descs + d * 8;
   const float* w = reinterpret_cast<const float*>(r[0]);
   const long long total = r[2] * r[3] * 9;                 // cout * cin_total * 9 floats
@@ -574,8 +573,7 @@ __global__ void weight_amax_batch_kernel(const long long* __restrict__ descs, in
 template <int NP>
 __global__ void pack_split_batch_kernel(const long long* __restrict__ descs, int ndesc, const float* __restrict__ partial,
                                         float* __restrict__ winv_out) {
-  int d = 0;
-  while (d + 1 < ndesc && descs[(d + 1) * 8 + 7] <= (long long)blockIdx.x) ++d;
+  const int d = cm_job_of_block(descs, ndesc);
   const long long* r = descs + d * 8;
   const float* w = reinterpret_cast<const float*>(r[0]);
   u32x4* wps = reinterpret_cast<u32x4*>(r[1]);

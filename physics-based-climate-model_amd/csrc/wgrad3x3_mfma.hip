@@ -455,8 +455,7 @@ __global__ void wgrad_unpack_kernel(const float* __restrict__ g, float* __restri
 
 // Batched unpack: descs = (ndesc + 1) records of 8 int64 {g ptr, dw ptr, cout, ctot, -, -, -, first block}.
 __global__ void wgrad_unpack_batch_kernel(const long long* __restrict__ descs, int ndesc, float scale) {
-  int d = 0;
-  while (d + 1 < ndesc && descs[(d + 1) * 8 + 7] <= (long long)blockIdx.x) ++d;
+  const int d = cm_job_of_block(descs, ndesc);
   const long long* r = descs + d * 8;
   const float* g = reinterpret_cast<const float*>(r[0]);
   float* dw = reinterpret_cast<float*>(r[1]);
