@@ -147,11 +147,9 @@ def _dlin(dy, p, name, pw, m, n, k, **kw):
 def _wgrad(dy: Tensor, x: Tensor, dw: Tensor, n_out: int, k_in: int, tokens: int, dbias: Tensor = None):
     """dw [n_out, k_in] += dy^T x  (dy [tokens, n_out], x [tokens, >= k_in]): split-K GEMM over the tokens; with ``dbias``
     the same launch adds the column sums of dy into it (the layer's bias gradient)."""
-    # reduction split: enough workgroups to fill the chip (~384 of 128 x 128 tiles), at least 256 tokens each
-    # (tools/gemm_bench.py: 768 x 256 is fastest at 32 splits, 256 x 256 at 54)
-    tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)
-    ks = max(1, min(64, tokens // 256, max(8, 384 // tiles)))
-    ops.gemm_wgrad(dy, x, dw.view(n_out, k_in), n_out, k_in, tokens, ks, dbias=dbias)
+    # (reduction split 0: chosen by the autotuner per shape -- 768 x 256 over 6912 tokens is fastest at 16 splits, 256 x 256
+    #  at 27-32)
+    ops.gemm_wgrad(dy, x, dw.view(n_out, k_in), n_out, k_in, tokens, 0, dbias=dbias)
 
 
 def backward(p: Dict[str, Tensor], g: Dict[str, Tensor], sv, n_heads: int, dpred=None, dd_head=None, need_dx=False):

@@ -896,7 +896,17 @@ def gemm_pb(a, packed, m, bias=None, resid=None, res_rows=0, mask=None, relu=Fal
 
 def gemm_wgrad(dy, x, dw, n_out, k_in, tokens, ksplit, dbias=None, tile=0):
     """dw [n_out, k_in] += dy^T x (dy [tokens, n_out], x [tokens, >= k_in]) and, with ``dbias``, dbias [n_out] += the column
-    sums of dy in the same launch (cm_gemm_h3_wgrad)."""
+    sums of dy in the same launch (cm_gemm_h3_wgrad).  ksplit <= 0: the autotuner picks the reduction split."""
+    if ksplit <= 0:
+        # reduction split chosen by timing (the best count depends on how many output tiles there are: 768 x 256 x 6912
+        # runs 36 us at 16 splits and 42 us at 27, 256 x 256 x 6912 the other way round)
+        def launch(ks, _scratch=[None]):
+            if _scratch[0] is None:
+                _scratch[0] = torch.zeros_like(dw)
+            return lib.cm_gemm_h3_wgrad(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(_scratch[0]), _scratch[0].stride(0), None,
+                                        n_out, k_in, tokens, ks, int(tile), _stream())
+        cands = [k for k in (4, 8, 12, 16, 20, 24, 32, 48, 64) if k * 64 <= tokens] or [1]
+        ksplit = _pick(("gemm_wgrad", n_out, k_in, tokens, int(tile)), cands, launch, max(1, min(16, tokens // 256)))
     check(lib.cm_gemm_h3_wgrad(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(dw), dw.stride(0), _p(dbias), n_out, k_in,
                                tokens, ksplit, int(tile), _stream()), "gemm_h3_wgrad")
     return dw
