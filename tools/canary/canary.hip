@@ -118,6 +118,10 @@ __global__ __launch_bounds__(1024) void pk_canary_kernel(unsigned* report, int i
   if (FORM == 14) { want.x = __fadd_rn(a.x, b.y); want.y = __fadd_rn(a.y, b.x); }
   if (FORM == 15) { want.x = __fmaf_rn(a.x, b.y, c.x); want.y = __fmaf_rn(a.y, b.x, c.y); }
   if (FORM == 16) { want.x = __fmul_rn(a.y, b.y); want.y = __fmul_rn(a.x, b.x); }
+  if (FORM == 17) { want.x = a.y; want.y = b.x; }          // v_pk_mov_b32 op_sel:[1,0]: lo <- src0.hi, hi <- src1.lo
+  if (FORM == 18) { want.x = a.x; want.y = b.y; }          // v_pk_mov_b32 op_sel:[0,1]: lo <- src0.lo, hi <- src1.hi
+  if (FORM == 19) { want.x = a.y; want.y = b.y; }          // v_pk_mov_b32 op_sel:[1,1]
+  if (FORM == 20) { want.x = a.x; want.y = b.x; }          // v_pk_mov_b32 op_sel:[0,0]
   // (the references of the swapped forms must not themselves be compiled into a packed instruction: pin them)
   asm volatile("" : "+v"(want.x));
   asm volatile("" : "+v"(want.y));
@@ -144,6 +148,10 @@ __global__ __launch_bounds__(1024) void pk_canary_kernel(unsigned* report, int i
     if (FORM == 14) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
     if (FORM == 15) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     if (FORM == 16) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0]" : "=v"(r) : "v"(a), "v"(b));
+    if (FORM == 17) asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    if (FORM == 18) asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    if (FORM == 19) asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(r) : "v"(a), "v"(b));
+    if (FORM == 20) asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0]" : "=v"(r) : "v"(a), "v"(b));
     if (FORM == 6) {
       asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r.x) : "v"(a.x), "v"(b.y));
       asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r.y) : "v"(a.y), "v"(b.x));
@@ -207,7 +215,11 @@ extern "C" int pk_canary_launch(unsigned* report, int form, int blocks, int thre
     case 13: pk_canary_kernel<13><<<blocks, threads, lds, st>>>(report, iters, lds_words); break;
     case 14: pk_canary_kernel<14><<<blocks, threads, lds, st>>>(report, iters, lds_words); break;
     case 15: pk_canary_kernel<15><<<blocks, threads, lds, st>>>(report, iters, lds_words); break;
-    default: pk_canary_kernel<16><<<blocks, threads, lds, st>>>(report, iters, lds_words); break;
+    case 16: pk_canary_kernel<16><<<blocks, threads, lds, st>>>(report, iters, lds_words); break;
+    case 17: pk_canary_kernel<17><<<blocks, threads, lds, st>>>(report, iters, lds_words); break;
+    case 18: pk_canary_kernel<18><<<blocks, threads, lds, st>>>(report, iters, lds_words); break;
+    case 19: pk_canary_kernel<19><<<blocks, threads, lds, st>>>(report, iters, lds_words); break;
+    default: pk_canary_kernel<20><<<blocks, threads, lds, st>>>(report, iters, lds_words); break;
   }
   return (int)hipGetLastError();
 }

@@ -32,7 +32,9 @@ names = {6: "v_mul_f32 x2 (reference path too: no packed instruction anywhere)",
          3: "v_pk_fma_f32 op_sel:[1,0,0] (src0 high half broadcast)",
          1: "v_pk_mul_f32 op_sel:[1,0] (src0 high half broadcast)",
          5: "v_pk_fma_f32 op_sel_hi:[0,1,1] (src0 low half broadcast)",
-         4: "v_pk_mul_f32 (no swizzle)"}
+         4: "v_pk_mul_f32 (no swizzle)",
+         17: "v_pk_mov_b32 op_sel:[1,0] (lo <- src0.hi, hi <- src1.lo; the compiler's half-swap, 589 in the shipped library)",
+         18: "v_pk_mov_b32 op_sel:[0,1]", 19: "v_pk_mov_b32 op_sel:[1,1]", 20: "v_pk_mov_b32 op_sel:[0,0]"}
 cp.REPLAYS = 40
 for form, nm in names.items():
     d = cp.pk_canary_case(form, threads=256)
